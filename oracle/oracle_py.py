@@ -1,0 +1,284 @@
+"""ctypes view of oracle/liborb_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product package
+(3_orb_slam3_selfnote_amd) never does.  See oracle/orb_oracle.h for the reference file:line each function follows.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborb_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB) for f in ("orb_oracle.c", "orb_oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB
+
+
+class Extractor(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("nlevels", C.c_int), ("iniThFAST", C.c_int), ("minThFAST", C.c_int),
+                ("scaleFactor", C.c_double),
+                ("mvScaleFactor", C.c_float * 16), ("mvInvScaleFactor", C.c_float * 16),
+                ("mvLevelSigma2", C.c_float * 16), ("mvInvLevelSigma2", C.c_float * 16),
+                ("mnFeaturesPerLevel", C.c_int * 16), ("umax", C.c_int * 16)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("N", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("desc", C.c_void_p), ("uRight", C.c_void_p),
+                ("mnMinX", C.c_float), ("mnMaxX", C.c_float), ("mnMinY", C.c_float), ("mnMaxY", C.c_float),
+                ("mfGridElementWidthInv", C.c_float), ("mfGridElementHeightInv", C.c_float),
+                ("mvScaleFactors", C.c_void_p), ("nlevels", C.c_int),
+                ("cell_start", C.c_int32 * (64 * 48 + 1)), ("cell_idx", C.c_void_p)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_fast_atan2.restype = C.c_float
+        _lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.orc_ic_angle.restype = C.c_float
+        _lib.orc_ic_angle.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+        _lib.orc_compute_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        _lib.orc_libm_cosf.restype = C.c_float
+        _lib.orc_libm_cosf.argtypes = [C.c_float]
+        _lib.orc_libm_sinf.restype = C.c_float
+        _lib.orc_libm_sinf.argtypes = [C.c_float]
+        _lib.orc_radius_by_viewing_cos.restype = C.c_float
+        _lib.orc_radius_by_viewing_cos.argtypes = [C.c_float]
+        _lib.orc_cvRound.argtypes = [C.c_double]
+        _lib.orc_get_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        _lib.orc_project.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        _lib.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        _lib.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_fast_corner_score.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        _lib.orc_copy_make_border101.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t]
+        _lib.orc_level_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int]
+        _lib.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        _lib.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.orc_search_by_projection_mp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_float] + [C.c_void_p] * 3
+        _lib.orc_search_by_projection_win.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
+        _lib.orc_search_by_projection_ff.argtypes = ([C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p] +
+                                                     [C.c_float] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        _lib.orc_frame_init.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """ORBextractor restatement (ORBextractor.cc:408-468 ctor, :1071-1184 operator())."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        self.L = lib()
+        self.e = Extractor()
+        self.L.orc_extractor_init(C.byref(self.e), int(nfeatures), C.c_float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    @property
+    def scale_factors(self):
+        return np.array(self.e.mvScaleFactor[:self.nlevels], dtype=np.float32)
+
+    @property
+    def features_per_level(self):
+        return list(self.e.mnFeaturesPerLevel[:self.nlevels])
+
+    @property
+    def umax(self):
+        return list(self.e.umax)
+
+    def level_size(self, level, cols, rows):
+        lc, lr = C.c_int(), C.c_int()
+        self.L.orc_level_size(C.byref(self.e), level, cols, rows, C.byref(lc), C.byref(lr))
+        return lc.value, lr.value
+
+    def pyramid(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape
+        levels = []
+        for l in range(self.nlevels):
+            lc, lr = self.level_size(l, cols, rows)
+            levels.append(np.zeros((lr, lc), dtype=np.uint8))
+        arr = (C.c_void_p * self.nlevels)(*[_p(a) for a in levels])
+        self.L.orc_compute_pyramid(C.byref(self.e), _p(img), cols, rows, C.c_size_t(img.strides[0]), arr)
+        return levels
+
+    def level_candidates(self, level_img):
+        level_img = np.ascontiguousarray(level_img, dtype=np.uint8)
+        h, w = level_img.shape
+        cap = (w * h) // 4 + 16
+        out = np.zeros((cap, 3), dtype=np.float32)
+        n = self.L.orc_level_candidates(C.byref(self.e), _p(level_img), w, h, C.c_size_t(level_img.strides[0]), _p(out), cap)
+        return out[:n].copy()
+
+    def ic_angle(self, level_img, x, y):
+        level_img = np.ascontiguousarray(level_img, dtype=np.uint8)
+        return float(self.L.orc_ic_angle(C.byref(self.e), _p(level_img), C.c_size_t(level_img.strides[0]), C.c_float(x), C.c_float(y)))
+
+    def extract(self, img, lap=(0, 1000), cap=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape
+        if cap is None:
+            cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        mono = self.L.orc_extract(C.byref(self.e), _p(img), rows, cols, C.c_size_t(img.strides[0]), int(lap[0]), int(lap[1]),
+                                  _p(kps), _p(desc), cap, C.byref(n))
+        if mono == -2:
+            return self.extract(img, lap, cap=n.value + 8)
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def distribute_octtree(xyr, minX, maxX, minY, maxY, N):
+    xyr = np.ascontiguousarray(xyr, dtype=np.float32)
+    n = xyr.shape[0]
+    out = np.zeros((n + 8, 3), dtype=np.float32)
+    m = lib().orc_distribute_octtree(_p(xyr), n, minX, maxX, minY, maxY, N, _p(out), n + 8)
+    return out[:m].copy()
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], C.c_size_t(src.strides[0]), _p(dst), dw, dh, C.c_size_t(dw))
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7(_p(src), src.shape[1], src.shape[0], C.c_size_t(src.strides[0]), _p(dst), C.c_size_t(dst.strides[0]))
+    return dst
+
+
+def fast9_16(img, threshold):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    out = np.zeros((cap, 3), dtype=np.int32)
+    n = lib().orc_fast9_16(_p(img), w, h, C.c_size_t(img.strides[0]), threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def compute_descriptor(blurred, x, y, angle):
+    blurred = np.ascontiguousarray(blurred, dtype=np.uint8)
+    d = np.zeros(32, dtype=np.uint8)
+    lib().orc_compute_descriptor(_p(blurred), C.c_size_t(blurred.strides[0]), C.c_float(x), C.c_float(y), C.c_float(angle), _p(d))
+    return d
+
+
+class OracleFrame:
+    """The slice of Frame the matcher reads (Frame.cc:379-380, 434-465)."""
+
+    def __init__(self, kx, ky, octave, angle, desc, bounds, scale_factors, u_right=None):
+        self.L = lib()
+        self.kx = np.ascontiguousarray(kx, dtype=np.float32)
+        self.ky = np.ascontiguousarray(ky, dtype=np.float32)
+        self.octave = np.ascontiguousarray(octave, dtype=np.int32)
+        self.angle = np.ascontiguousarray(angle, dtype=np.float32)
+        self.desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        self.sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+        self.N = len(self.kx)
+        self.f = Frame()
+        self.L.orc_frame_init(C.byref(self.f), self.N, _p(self.kx), _p(self.ky), _p(self.octave), _p(self.angle),
+                              _p(self.desc), _p(self.u_right), *[C.c_float(b) for b in bounds], _p(self.sf), len(self.sf))
+        self.slot = np.full(self.N, -1, dtype=np.int32)
+        self.slot_obs = np.zeros(self.N, dtype=np.uint8)
+
+    def __del__(self):
+        try:
+            self.L.orc_frame_free(C.byref(self.f))
+        except Exception:
+            pass
+
+    def grid_csr(self):
+        start = np.array(self.f.cell_start[:], dtype=np.int32)
+        n = int(start[-1])
+        idx = np.ctypeslib.as_array(C.cast(self.f.cell_idx, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+        return start, idx
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(self.N, 1), dtype=np.int32)
+        n = self.L.orc_get_features_in_area(C.byref(self.f), C.c_float(x), C.c_float(y), C.c_float(r), min_level, max_level, _p(out))
+        return out[:n].copy()
+
+    def search_by_projection_mp(self, in_view, qdesc, projX, projY, viewCos, level, th, nnratio, qobs=None, projXR=None):
+        nq = len(projX)
+        a = lambda v, t: np.ascontiguousarray(v, dtype=t)
+        in_view, qdesc = a(in_view, np.uint8), a(qdesc, np.uint8)
+        projX, projY, viewCos, level = a(projX, np.float32), a(projY, np.float32), a(viewCos, np.float32), a(level, np.int32)
+        projXR = a(projXR, np.float32) if projXR is not None else np.zeros(nq, np.float32)
+        qobs = a(qobs, np.uint8) if qobs is not None else np.ones(nq, np.uint8)
+        moq = np.full(nq, -1, dtype=np.int32)
+        n = self.L.orc_search_by_projection_mp(C.byref(self.f), nq, _p(in_view), _p(qdesc), _p(projX), _p(projY), _p(projXR),
+                                               _p(viewCos), _p(level), _p(qobs), C.c_float(th), C.c_float(nnratio),
+                                               _p(self.slot), _p(self.slot_obs), _p(moq))
+        return n, moq
+
+    def search_by_projection_win(self, qdesc, u, v, radius, min_level, max_level, nnratio=0.8, th_high=100,
+                                 mode_second=True, qobs=None, in_view=None):
+        nq = len(u)
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        qdesc, u, v, radius = a(qdesc, np.uint8), a(u, np.float32), a(v, np.float32), a(radius, np.float32)
+        min_level, max_level = a(min_level, np.int32), a(max_level, np.int32)
+        qobs = a(qobs, np.uint8) if qobs is not None else np.ones(nq, np.uint8)
+        in_view = a(in_view, np.uint8) if in_view is not None else np.ones(nq, np.uint8)
+        moq = np.full(nq, -1, dtype=np.int32)
+        bd = np.full(nq, 256, dtype=np.int32)
+        n = self.L.orc_search_by_projection_win(C.byref(self.f), nq, _p(in_view), _p(qdesc), _p(u), _p(v), _p(radius),
+                                                _p(min_level), _p(max_level), _p(qobs), C.c_float(nnratio), int(th_high),
+                                                int(bool(mode_second)), _p(self.slot), _p(self.slot_obs), _p(moq), _p(bd))
+        return n, moq, bd
+
+    def search_by_projection_ff(self, has_mp, Xw, mpdesc, last_octave, last_angle, Tcw, Tlw, cam_type, cam_params,
+                                th, mono=True, check_ori=True, mb=0.0, mbf=0.0, qobs=None):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        n_last = len(has_mp)
+        has_mp, Xw, mpdesc = a(has_mp, np.uint8), a(Xw, np.float32), a(mpdesc, np.uint8)
+        last_octave, last_angle = a(last_octave, np.int32), a(last_angle, np.float32)
+        Tcw, Tlw, cam_params = a(Tcw, np.float32), a(Tlw, np.float32), a(cam_params, np.float32)
+        qobs = a(qobs, np.uint8) if qobs is not None else np.ones(n_last, np.uint8)
+        return self.L.orc_search_by_projection_ff(C.byref(self.f), n_last, _p(has_mp), _p(Xw), _p(mpdesc), _p(last_octave),
+                                                  _p(last_angle), _p(qobs), _p(Tcw), _p(Tlw), int(cam_type), _p(cam_params),
+                                                  C.c_float(mb), C.c_float(mbf), C.c_float(th), int(mono), int(check_ori),
+                                                  _p(self.slot), _p(self.slot_obs))
+
+
+def project(cam_type, params, X, Y, Z):
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    u, v = C.c_float(), C.c_float()
+    lib().orc_project(cam_type, _p(params), C.c_float(X), C.c_float(Y), C.c_float(Z), C.byref(u), C.byref(v))
+    return u.value, v.value
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value

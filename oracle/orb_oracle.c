@@ -1,0 +1,1066 @@
+/*
+ * orb_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).  See orb_oracle.h.
+ *
+ * PARITY UNPINNED: no golden vectors exist in the reference; OpenCV primitive semantics are
+ * restated from the OpenCV 3.4.x pure-C++ code paths.
+ *
+ * Build: gcc -O2 -std=gnu11 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  All float
+ * expressions are written so that every intermediate has the type it has in the reference.
+ */
+#include "orb_oracle.h"
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* rounding helpers                                                             */
+/* ------------------------------------------------------------------------------------------ */
+int orc_cvRound(double v) { return (int)lrint(v); } /* round-half-even in the default FP mode */
+static int cvFloor_(double v) { return (int)floor(v); }
+static int cvCeil_(double v) { return (int)ceil(v); }
+
+float orc_libm_cosf(float x) { return cosf(x); }
+float orc_libm_sinf(float x) { return sinf(x); }
+
+static const int8_t kPattern[1024] = {
+#include "../include/orb_pattern_data.inc"
+};
+
+#define PATCH_SIZE 31      /* ORBextractor.cc:70 */
+#define HALF_PATCH_SIZE 15 /* ORBextractor.cc:71 */
+#define EDGE_THRESHOLD 19  /* ORBextractor.cc:72 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* X0: constructor, ORBextractor.cc:408-468                                                     */
+/* ------------------------------------------------------------------------------------------ */
+void orc_extractor_init(orc_extractor *e, int nfeatures, float scaleFactor_, int nlevels, int iniTh, int minTh) {
+  memset(e, 0, sizeof(*e));
+  e->nfeatures = nfeatures;
+  e->scaleFactor = (double)scaleFactor_; /* member is double, initialised from float (ORBextractor.h:96) */
+  e->nlevels = nlevels;
+  e->iniThFAST = iniTh;
+  e->minThFAST = minTh;
+  e->mvScaleFactor[0] = 1.0f;
+  e->mvLevelSigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    e->mvScaleFactor[i] = (float)((double)e->mvScaleFactor[i - 1] * e->scaleFactor); /* :419 */
+    e->mvLevelSigma2[i] = e->mvScaleFactor[i] * e->mvScaleFactor[i];                 /* :420 */
+  }
+  for (int i = 0; i < nlevels; i++) {
+    e->mvInvScaleFactor[i] = 1.0f / e->mvScaleFactor[i];
+    e->mvInvLevelSigma2[i] = 1.0f / e->mvLevelSigma2[i];
+  }
+  float factor = (float)(1.0 / e->scaleFactor); /* 1.0f / double -> double -> float, :433 */
+  float nDesired = (float)nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels)); /* :434 */
+  int sum = 0;
+  for (int level = 0; level < nlevels - 1; level++) {
+    e->mnFeaturesPerLevel[level] = orc_cvRound(nDesired);
+    sum += e->mnFeaturesPerLevel[level];
+    nDesired *= factor;
+  }
+  e->mnFeaturesPerLevel[nlevels - 1] = (nfeatures - sum) > 0 ? (nfeatures - sum) : 0;
+
+  /* umax, :452-467 */
+  int v, v0;
+  int vmax = cvFloor_(HALF_PATCH_SIZE * sqrtf(2.f) / 2 + 1);
+  int vmin = cvCeil_(HALF_PATCH_SIZE * sqrtf(2.f) / 2);
+  const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+  for (v = 0; v <= vmax; ++v) e->umax[v] = orc_cvRound(sqrt(hp2 - v * v));
+  for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+    while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+    e->umax[v] = v0;
+    ++v0;
+  }
+}
+
+void orc_level_size(const orc_extractor *e, int level, int cols, int rows, int *lcols, int *lrows) {
+  float scale = e->mvInvScaleFactor[level];
+  *lcols = orc_cvRound((float)cols * scale); /* :1192-1193 */
+  *lrows = orc_cvRound((float)rows * scale);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A.3 cv::resize INTER_LINEAR, 8UC1 (fixed point, 11 coefficient bits)                          */
+/* ------------------------------------------------------------------------------------------ */
+static short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, size_t sstride, uint8_t *dst, int dw, int dh,
+                          size_t dstride) {
+  /* hal::resize: inv_scale = dsize/ssize (double); scale = 1./inv_scale */
+  double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  int *xofs = (int *)malloc(sizeof(int) * dw);
+  short *ialpha = (short *)malloc(sizeof(short) * 2 * dw);
+  int *yofs = (int *)malloc(sizeof(int) * dh);
+  short *ibeta = (short *)malloc(sizeof(short) * 2 * dh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cvFloor_(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = sat_short(orc_cvRound((1.f - fx) * 2048));
+    ialpha[2 * dx + 1] = sat_short(orc_cvRound(fx * 2048));
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cvFloor_(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    ibeta[2 * dy] = sat_short(orc_cvRound((1.f - fy) * 2048));
+    ibeta[2 * dy + 1] = sat_short(orc_cvRound(fy * 2048));
+  }
+  int *row0 = (int *)malloc(sizeof(int) * dw), *row1 = (int *)malloc(sizeof(int) * dw);
+  for (int dy = 0; dy < dh; dy++) {
+    int sy0 = yofs[dy], sy1 = yofs[dy] + 1;
+    if (sy0 < 0) sy0 = 0;
+    if (sy0 > sh - 1) sy0 = sh - 1;
+    if (sy1 < 0) sy1 = 0;
+    if (sy1 > sh - 1) sy1 = sh - 1;
+    const uint8_t *S0 = src + (size_t)sy0 * sstride, *S1 = src + (size_t)sy1 * sstride;
+    for (int dx = 0; dx < dw; dx++) {
+      int sx = xofs[dx];
+      int sx1 = sx + 1 < sw ? sx + 1 : sx; /* right tap has weight 0 when clamped */
+      row0[dx] = S0[sx] * ialpha[2 * dx] + S0[sx1] * ialpha[2 * dx + 1];
+      row1[dx] = S1[sx] * ialpha[2 * dx] + S1[sx1] * ialpha[2 * dx + 1];
+    }
+    int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    uint8_t *D = dst + (size_t)dy * dstride;
+    for (int dx = 0; dx < dw; dx++) {
+      int v = (((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2;
+      D[dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+  }
+  free(xofs); free(ialpha); free(yofs); free(ibeta); free(row0); free(row1);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A.2 copyMakeBorder REFLECT_101                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) {
+    if (p < 0) p = -p;
+    else p = 2 * (n - 1) - p;
+  }
+  return p;
+}
+
+void orc_copy_make_border101(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, int border, size_t dstride) {
+  for (int y = -border; y < h + border; y++) {
+    const uint8_t *S = src + (size_t)reflect101(y, h) * sstride;
+    uint8_t *D = dst + (size_t)(y + border) * dstride;
+    for (int x = -border; x < w + border; x++) D[x + border] = S[reflect101(x, w)];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A.5 GaussianBlur 7x7 sigma=2, fixed point                                                    */
+/* ------------------------------------------------------------------------------------------ */
+void orc_gauss7_kernel(int k[7]) {
+  /* getGaussianKernel(7, 2): exp(-(i-3)^2/(2 sigma^2)) normalised, then round(g*256) per tap */
+  double g[7], sum = 0;
+  const double sigma = 2.0, scale2X = -0.5 / (sigma * sigma);
+  for (int i = 0; i < 7; i++) {
+    double x = i - 3.0;
+    g[i] = exp(scale2X * x * x);
+    sum += g[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < 7; i++) k[i] = orc_cvRound(g[i] * sum * 256.0);
+}
+
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride) {
+  int k[7];
+  orc_gauss7_kernel(k);
+  uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    const uint8_t *S = src + (size_t)y * sstride;
+    for (int x = 0; x < w; x++) {
+      uint32_t s = 0;
+      for (int i = 0; i < 7; i++) s += (uint32_t)k[i] * S[reflect101(x + i - 3, w)];
+      tmp[(size_t)y * w + x] = s;
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    uint8_t *D = dst + (size_t)y * dstride;
+    for (int x = 0; x < w; x++) {
+      uint32_t s = 0;
+      for (int j = 0; j < 7; j++) s += (uint32_t)k[j] * tmp[(size_t)reflect101(y + j - 3, h) * w + x];
+      uint32_t v = (s + 32768u) >> 16;
+      D[x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A.1 cv::FAST 9_16 with non-max suppression                                                   */
+/* ------------------------------------------------------------------------------------------ */
+static const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+int orc_fast_corner_score(const uint8_t *p, size_t stride, int threshold) {
+  /* cornerScore<16>: d[k] = v - circle[k], 25 entries (wrap) */
+  int d[25];
+  int v = p[0];
+  for (int k = 0; k < 25; k++) {
+    int kk = k & 15;
+    d[k] = v - p[(ptrdiff_t)kCircle[kk][1] * (ptrdiff_t)stride + kCircle[kk][0]];
+  }
+  int a0 = threshold;
+  for (int k = 0; k < 16; k += 2) {
+    int a = d[k + 1] < d[k + 2] ? d[k + 1] : d[k + 2];
+    a = a < d[k + 3] ? a : d[k + 3];
+    if (a <= a0) continue;
+    for (int j = 4; j <= 8; j++) a = a < d[k + j] ? a : d[k + j];
+    int t = a < d[k] ? a : d[k];
+    if (t > a0) a0 = t;
+    t = a < d[k + 9] ? a : d[k + 9];
+    if (t > a0) a0 = t;
+  }
+  int b0 = -a0;
+  for (int k = 0; k < 16; k += 2) {
+    int b = d[k + 1] > d[k + 2] ? d[k + 1] : d[k + 2];
+    for (int j = 3; j <= 5; j++) b = b > d[k + j] ? b : d[k + j];
+    if (b >= b0) continue;
+    for (int j = 6; j <= 8; j++) b = b > d[k + j] ? b : d[k + j];
+    int t = b > d[k] ? b : d[k];
+    if (t < b0) b0 = t;
+    t = b > d[k + 9] ? b : d[k + 9];
+    if (t < b0) b0 = t;
+  }
+  return -b0 - 1;
+}
+
+int orc_fast9_16(const uint8_t *img, int w, int h, size_t stride, int threshold, int *xys, int cap) {
+  const int K = 8, N = 25;
+  int n = 0;
+  if (threshold < 0) threshold = 0;
+  if (threshold > 255) threshold = 255;
+  if (w < 7 || h < 7) return 0;
+  /* three rolling score rows + corner position lists, exactly like FAST_t<16> */
+  uint8_t *buf = (uint8_t *)calloc((size_t)w * 3, 1);
+  int *cp = (int *)malloc(sizeof(int) * ((size_t)w + 1) * 3);
+  uint8_t *sc[3] = {buf, buf + w, buf + 2 * w};
+  int *cpbuf[3] = {cp + 1, cp + 1 + (w + 1), cp + 1 + 2 * (w + 1)};
+  ptrdiff_t off[16];
+  for (int k = 0; k < 16; k++) off[k] = (ptrdiff_t)kCircle[k][1] * (ptrdiff_t)stride + kCircle[k][0];
+  for (int i = 3; i < h - 2; i++) {
+    const uint8_t *ptr = img + (size_t)i * stride + 3;
+    uint8_t *curr = sc[(i - 3) % 3];
+    int *cornerpos = cpbuf[(i - 3) % 3];
+    memset(curr, 0, (size_t)w);
+    int ncorners = 0;
+    if (i < h - 3) {
+      for (int j = 3; j < w - 3; j++, ptr++) {
+        int v = ptr[0];
+        int vt_lo = v - threshold, vt_hi = v + threshold;
+        int is_corner = 0;
+        /* high-speed rejection test of FAST_t<16>: every 9-arc contains one pixel of each opposite pair
+         * (k, k+8), so all 8 pairs must have a darker (bit 1) resp. brighter (bit 2) member */
+        int dmask = 3;
+        for (int k = 0; k < 8 && dmask; k++) {
+          int xa = ptr[off[k]], xb = ptr[off[k + 8]];
+          int m = (xa < vt_lo ? 1 : xa > vt_hi ? 2 : 0) | (xb < vt_lo ? 1 : xb > vt_hi ? 2 : 0);
+          dmask &= m;
+        }
+        if (!dmask) continue;
+        /* darker arc: x < v - t ; brighter arc: x > v + t ; 9 contiguous among 25 (wrap) */
+        if (dmask & 1) {
+          int count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[off[k & 15]];
+            if (x < vt_lo) { if (++count > K) { is_corner = 1; break; } }
+            else count = 0;
+          }
+        }
+        if (!is_corner && (dmask & 2)) {
+          int count = 0;
+          for (int k = 0; k < N; k++) {
+            int x = ptr[off[k & 15]];
+            if (x > vt_hi) { if (++count > K) { is_corner = 1; break; } }
+            else count = 0;
+          }
+        }
+        if (is_corner) {
+          cornerpos[ncorners++] = j;
+          curr[j] = (uint8_t)orc_fast_corner_score(ptr, stride, threshold);
+        }
+      }
+    }
+    cornerpos[-1] = ncorners;
+    if (i == 3) continue;
+    const uint8_t *prev = sc[(i - 4 + 3) % 3];
+    const uint8_t *pprev = sc[(i - 5 + 3) % 3];
+    cornerpos = cpbuf[(i - 4 + 3) % 3];
+    ncorners = cornerpos[-1];
+    for (int k = 0; k < ncorners; k++) {
+      int j = cornerpos[k];
+      int score = prev[j];
+      if (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+          score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+        if (n < cap) {
+          xys[3 * n] = j;
+          xys[3 * n + 1] = i - 1;
+          xys[3 * n + 2] = score;
+        }
+        n++;
+      }
+    }
+  }
+  free(buf);
+  free(cp);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A.6 cv::fastAtan2                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+float orc_fast_atan2(float y, float x) {
+  const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X5 IC_Angle, ORBextractor.cc:75-102                                                          */
+/* ------------------------------------------------------------------------------------------ */
+float orc_ic_angle(const orc_extractor *e, const uint8_t *img, size_t stride, float ptx, float pty) {
+  int m_01 = 0, m_10 = 0;
+  const uint8_t *center = img + (ptrdiff_t)orc_cvRound(pty) * (ptrdiff_t)stride + orc_cvRound(ptx);
+  for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+  int step = (int)stride;
+  for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+    int v_sum = 0;
+    int d = e->umax[v];
+    for (int u = -d; u <= d; ++u) {
+      int val_plus = center[u + v * step], val_minus = center[u - v * step];
+      v_sum += (val_plus - val_minus);
+      m_10 += u * (val_plus + val_minus);
+    }
+    m_01 += v * v_sum;
+  }
+  return orc_fast_atan2((float)m_01, (float)m_10);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X7 computeOrbDescriptor, ORBextractor.cc:106-145                                             */
+/* ------------------------------------------------------------------------------------------ */
+void orc_compute_descriptor(const uint8_t *img, size_t stride, float ptx, float pty, float angle_deg, uint8_t desc[32]) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f); /* :105 */
+  float angle = angle_deg * factorPI;
+  float a = cosf(angle), b = sinf(angle); /* std::cos(float) via `using namespace std` */
+  const uint8_t *center = img + (ptrdiff_t)orc_cvRound(pty) * (ptrdiff_t)stride + orc_cvRound(ptx);
+  const int step = (int)stride;
+  const int8_t *pat = kPattern;
+#define GET_VALUE(idx)                                                                            \
+  center[orc_cvRound((float)pat[2 * (idx)] * b + (float)pat[2 * (idx) + 1] * a) * step +          \
+         orc_cvRound((float)pat[2 * (idx)] * a - (float)pat[2 * (idx) + 1] * b)]
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int j = 0; j < 8; j++) {
+      int t0 = GET_VALUE(2 * j), t1 = GET_VALUE(2 * j + 1);
+      val |= (t0 < t1) << j;
+    }
+    desc[i] = (uint8_t)val;
+  }
+#undef GET_VALUE
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X2 candidate generation, ORBextractor.cc:771-854                                             */
+/* ------------------------------------------------------------------------------------------ */
+int orc_level_candidates(const orc_extractor *e, const uint8_t *img, int cols, int rows, size_t stride, float *xyr, int cap) {
+  const float W = 30;
+  const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+  const int maxBorderX = cols - EDGE_THRESHOLD + 3, maxBorderY = rows - EDGE_THRESHOLD + 3;
+  const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+  const int nCols = (int)(width / W), nRows = (int)(height / W);
+  if (nCols <= 0 || nRows <= 0) return 0; /* reference divides by zero here; defined as "no keypoints" */
+  const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+  int n = 0;
+  int cellcap = 64 * 64;
+  int *cell = (int *)malloc(sizeof(int) * 3 * cellcap);
+  for (int i = 0; i < nRows; i++) {
+    const float iniY = (float)(minBorderY + i * hCell);
+    float maxY = iniY + hCell + 6;
+    if (iniY >= maxBorderY - 3) continue;
+    if (maxY > maxBorderY) maxY = (float)maxBorderY;
+    for (int j = 0; j < nCols; j++) {
+      const float iniX = (float)(minBorderX + j * wCell);
+      float maxX = iniX + wCell + 6;
+      if (iniX >= maxBorderX - 6) continue;
+      if (maxX > maxBorderX) maxX = (float)maxBorderX;
+      int x0 = (int)iniX, x1 = (int)maxX, y0 = (int)iniY, y1 = (int)maxY;
+      const uint8_t *sub = img + (size_t)y0 * stride + x0;
+      int nc = orc_fast9_16(sub, x1 - x0, y1 - y0, stride, e->iniThFAST, cell, cellcap);
+      if (nc == 0) nc = orc_fast9_16(sub, x1 - x0, y1 - y0, stride, e->minThFAST, cell, cellcap);
+      for (int k = 0; k < nc; k++) {
+        if (n < cap) {
+          xyr[3 * n] = (float)cell[3 * k] + (float)(j * wCell);
+          xyr[3 * n + 1] = (float)cell[3 * k + 1] + (float)(i * hCell);
+          xyr[3 * n + 2] = (float)cell[3 * k + 2];
+        }
+        n++;
+      }
+    }
+  }
+  free(cell);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X4 DistributeOctTree, ORBextractor.cc:479-761                                                */
+/* Nodes live in a pool; the std::list is a doubly linked index list.  The reference sorts
+ * pair<int, ExtractorNode*>; pointer ties are defined here as creation order (a later-created
+ * node compares greater), i.e. what a monotone allocator gives.      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+  int *keys;
+  int nkeys;
+  int bNoMore;
+  int prev, next; /* list links */
+} onode;
+
+typedef struct {
+  onode *nodes;
+  int count, capn;
+  int head, tail, size;
+} olist;
+
+static int ol_new(olist *L) {
+  if (L->count == L->capn) {
+    L->capn *= 2;
+    L->nodes = (onode *)realloc(L->nodes, sizeof(onode) * (size_t)L->capn);
+  }
+  onode *n = &L->nodes[L->count];
+  memset(n, 0, sizeof(*n));
+  n->prev = n->next = -1;
+  return L->count++;
+}
+static void ol_push_front(olist *L, int id) {
+  L->nodes[id].prev = -1;
+  L->nodes[id].next = L->head;
+  if (L->head >= 0) L->nodes[L->head].prev = id;
+  L->head = id;
+  if (L->tail < 0) L->tail = id;
+  L->size++;
+}
+static void ol_push_back(olist *L, int id) {
+  L->nodes[id].next = -1;
+  L->nodes[id].prev = L->tail;
+  if (L->tail >= 0) L->nodes[L->tail].next = id;
+  L->tail = id;
+  if (L->head < 0) L->head = id;
+  L->size++;
+}
+static int ol_erase(olist *L, int id) { /* returns next */
+  int p = L->nodes[id].prev, nx = L->nodes[id].next;
+  if (p >= 0) L->nodes[p].next = nx; else L->head = nx;
+  if (nx >= 0) L->nodes[nx].prev = p; else L->tail = p;
+  L->size--;
+  return nx;
+}
+
+/* ExtractorNode::DivideNode, ORBextractor.cc:479-535.  Creates 4 pool nodes (not linked). */
+static void divide_node(olist *L, int id, const float *xyr, int ch[4]) {
+  for (int c = 0; c < 4; c++) ch[c] = ol_new(L);
+  onode *p = &L->nodes[id];
+  const int halfX = (int)ceilf((float)(p->URx - p->ULx) / 2);
+  const int halfY = (int)ceilf((float)(p->BRy - p->ULy) / 2);
+  onode *n1 = &L->nodes[ch[0]], *n2 = &L->nodes[ch[1]], *n3 = &L->nodes[ch[2]], *n4 = &L->nodes[ch[3]];
+  n1->ULx = p->ULx; n1->ULy = p->ULy;
+  n1->URx = p->ULx + halfX; n1->URy = p->ULy;
+  n1->BLx = p->ULx; n1->BLy = p->ULy + halfY;
+  n1->BRx = p->ULx + halfX; n1->BRy = p->ULy + halfY;
+  n2->ULx = n1->URx; n2->ULy = n1->URy;
+  n2->URx = p->URx; n2->URy = p->URy;
+  n2->BLx = n1->BRx; n2->BLy = n1->BRy;
+  n2->BRx = p->URx; n2->BRy = p->ULy + halfY;
+  n3->ULx = n1->BLx; n3->ULy = n1->BLy;
+  n3->URx = n1->BRx; n3->URy = n1->BRy;
+  n3->BLx = p->BLx; n3->BLy = p->BLy;
+  n3->BRx = n1->BRx; n3->BRy = p->BLy;
+  n4->ULx = n3->URx; n4->ULy = n3->URy;
+  n4->URx = n2->BRx; n4->URy = n2->BRy;
+  n4->BLx = n3->BRx; n4->BLy = n3->BRy;
+  n4->BRx = p->BRx; n4->BRy = p->BRy;
+  for (int c = 0; c < 4; c++) {
+    L->nodes[ch[c]].keys = (int *)malloc(sizeof(int) * (size_t)(p->nkeys > 0 ? p->nkeys : 1));
+    L->nodes[ch[c]].nkeys = 0;
+  }
+  for (int i = 0; i < p->nkeys; i++) {
+    int k = p->keys[i];
+    float kx = xyr[3 * k], ky = xyr[3 * k + 1];
+    onode *t;
+    if (kx < (float)n1->URx) t = (ky < (float)n1->BRy) ? n1 : n3;
+    else t = (ky < (float)n1->BRy) ? n2 : n4;
+    t->keys[t->nkeys++] = k;
+  }
+  for (int c = 0; c < 4; c++)
+    if (L->nodes[ch[c]].nkeys == 1) L->nodes[ch[c]].bNoMore = 1;
+}
+
+typedef struct { int size; int id; } szid;
+static int cmp_szid(const void *a, const void *b) {
+  const szid *x = (const szid *)a, *y = (const szid *)b;
+  if (x->size != y->size) return x->size < y->size ? -1 : 1;
+  return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+
+int orc_distribute_octtree(const float *xyr, int n, int minX, int maxX, int minY, int maxY, int N, float *out, int cap) {
+  const int nIni = (int)roundf((float)(maxX - minX) / (float)(maxY - minY)); /* :541 */
+  if (nIni <= 0) return 0; /* reference: division by zero / empty vpIniNodes (undefined); defined as empty */
+  const float hX = (float)(maxX - minX) / (float)nIni;
+  olist L;
+  L.capn = 64; L.count = 0; L.head = L.tail = -1; L.size = 0;
+  L.nodes = (onode *)malloc(sizeof(onode) * (size_t)L.capn);
+  int *ini = (int *)malloc(sizeof(int) * (size_t)nIni);
+  for (int i = 0; i < nIni; i++) {
+    int id = ol_new(&L);
+    onode *ni = &L.nodes[id];
+    ni->ULx = (int)(hX * (float)i); ni->ULy = 0;
+    ni->URx = (int)(hX * (float)(i + 1)); ni->URy = 0;
+    ni->BLx = ni->ULx; ni->BLy = maxY - minY;
+    ni->BRx = ni->URx; ni->BRy = maxY - minY;
+    ni->keys = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    ni->nkeys = 0;
+    ol_push_back(&L, id);
+    ini[i] = id;
+  }
+  for (int i = 0; i < n; i++) {
+    int r = (int)(xyr[3 * i] / hX); /* :567 */
+    if (r < 0) r = 0;
+    if (r >= nIni) r = nIni - 1; /* reference would index out of range; cannot happen for in-range x */
+    onode *t = &L.nodes[ini[r]];
+    t->keys[t->nkeys++] = i;
+  }
+  free(ini);
+  for (int lit = L.head; lit >= 0;) {
+    if (L.nodes[lit].nkeys == 1) { L.nodes[lit].bNoMore = 1; lit = L.nodes[lit].next; }
+    else if (L.nodes[lit].nkeys == 0) lit = ol_erase(&L, lit);
+    else lit = L.nodes[lit].next;
+  }
+  int bFinish = 0;
+  szid *vSize = (szid *)malloc(sizeof(szid) * (size_t)(4 * (n + 8)));
+  szid *vPrev = (szid *)malloc(sizeof(szid) * (size_t)(4 * (n + 8)));
+  int nSize = 0;
+  while (!bFinish) {
+    int prevSize = L.size;
+    int lit = L.head;
+    int nToExpand = 0;
+    nSize = 0;
+    while (lit >= 0) {
+      if (L.nodes[lit].bNoMore) { lit = L.nodes[lit].next; continue; }
+      int ch[4];
+      divide_node(&L, lit, xyr, ch);
+      for (int c = 0; c < 4; c++) {
+        if (L.nodes[ch[c]].nkeys > 0) {
+          ol_push_front(&L, ch[c]);
+          if (L.nodes[ch[c]].nkeys > 1) {
+            nToExpand++;
+            vSize[nSize].size = L.nodes[ch[c]].nkeys;
+            vSize[nSize].id = ch[c];
+            nSize++;
+          }
+        }
+      }
+      lit = ol_erase(&L, lit);
+    }
+    if (L.size >= N || L.size == prevSize) {
+      bFinish = 1;
+    } else if (L.size + nToExpand * 3 > N) {
+      while (!bFinish) {
+        prevSize = L.size;
+        int nPrev = nSize;
+        memcpy(vPrev, vSize, sizeof(szid) * (size_t)nSize);
+        nSize = 0;
+        qsort(vPrev, (size_t)nPrev, sizeof(szid), cmp_szid);
+        for (int j = nPrev - 1; j >= 0; j--) {
+          int ch[4];
+          divide_node(&L, vPrev[j].id, xyr, ch);
+          for (int c = 0; c < 4; c++) {
+            if (L.nodes[ch[c]].nkeys > 0) {
+              ol_push_front(&L, ch[c]);
+              if (L.nodes[ch[c]].nkeys > 1) {
+                vSize[nSize].size = L.nodes[ch[c]].nkeys;
+                vSize[nSize].id = ch[c];
+                nSize++;
+              }
+            }
+          }
+          ol_erase(&L, vPrev[j].id);
+          if (L.size >= N) break;
+        }
+        if (L.size >= N || L.size == prevSize) bFinish = 1;
+      }
+    }
+  }
+  int nout = 0;
+  for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
+    onode *nd = &L.nodes[lit];
+    int best = nd->keys[0];
+    float maxResponse = xyr[3 * best + 2];
+    for (int k = 1; k < nd->nkeys; k++) {
+      if (xyr[3 * nd->keys[k] + 2] > maxResponse) {
+        best = nd->keys[k];
+        maxResponse = xyr[3 * best + 2];
+      }
+    }
+    if (nout < cap) {
+      out[3 * nout] = xyr[3 * best];
+      out[3 * nout + 1] = xyr[3 * best + 1];
+      out[3 * nout + 2] = xyr[3 * best + 2];
+    }
+    nout++;
+  }
+  for (int i = 0; i < L.count; i++) free(L.nodes[i].keys);
+  free(L.nodes);
+  free(vSize);
+  free(vPrev);
+  return nout;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X1 ComputePyramid, ORBextractor.cc:1186-1219 (ROI content only; the 19-px border is never
+ * read by the extractor and is produced on demand by orc_copy_make_border101).                 */
+/* ------------------------------------------------------------------------------------------ */
+void orc_compute_pyramid(const orc_extractor *e, const uint8_t *img, int cols, int rows, size_t stride, uint8_t **levels) {
+  int pw = cols, ph = rows;
+  for (int y = 0; y < rows; y++) memcpy(levels[0] + (size_t)y * cols, img + (size_t)y * stride, (size_t)cols);
+  for (int l = 1; l < e->nlevels; l++) {
+    int lw, lh;
+    orc_level_size(e, l, cols, rows, &lw, &lh);
+    orc_resize_linear_u8(levels[l - 1], pw, ph, (size_t)pw, levels[l], lw, lh, (size_t)lw);
+    pw = lw; ph = lh;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* X8 operator(), ORBextractor.cc:1071-1184                                                     */
+/* ------------------------------------------------------------------------------------------ */
+int orc_extract(const orc_extractor *e, const uint8_t *img, int rows, int cols, size_t stride, int lap0, int lap1,
+                orc_keypoint *kps, uint8_t *desc, int cap, int *n_out) {
+  *n_out = 0;
+  if (!img || rows <= 0 || cols <= 0) return -1;
+  const int nl = e->nlevels;
+  uint8_t *levels[ORC_MAX_LEVELS];
+  int lw[ORC_MAX_LEVELS], lh[ORC_MAX_LEVELS];
+  for (int l = 0; l < nl; l++) {
+    orc_level_size(e, l, cols, rows, &lw[l], &lh[l]);
+    levels[l] = (uint8_t *)malloc((size_t)lw[l] * lh[l] + 1);
+  }
+  orc_compute_pyramid(e, img, cols, rows, stride, levels);
+
+  /* ComputeKeyPointsOctTree */
+  float *lvl_kp[ORC_MAX_LEVELS];   /* x, y, response, angle per keypoint (level coordinates) */
+  int lvl_n[ORC_MAX_LEVELS];
+  int nkeypoints = 0;
+  for (int l = 0; l < nl; l++) {
+    const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+    const int maxBorderX = lw[l] - EDGE_THRESHOLD + 3, maxBorderY = lh[l] - EDGE_THRESHOLD + 3;
+    int candcap = (lw[l] * lh[l]) / 4 + 16;
+    float *cand = (float *)malloc(sizeof(float) * 3 * (size_t)candcap);
+    int nc = 0;
+    if (maxBorderX > minBorderX && maxBorderY > minBorderY)
+      nc = orc_level_candidates(e, levels[l], lw[l], lh[l], (size_t)lw[l], cand, candcap);
+    int outcap = nc + 8;
+    float *sel = (float *)malloc(sizeof(float) * 3 * (size_t)outcap);
+    int ns = 0;
+    if (nc > 0)
+      ns = orc_distribute_octtree(cand, nc, minBorderX, maxBorderX, minBorderY, maxBorderY, e->mnFeaturesPerLevel[l], sel, outcap);
+    lvl_kp[l] = (float *)malloc(sizeof(float) * 4 * (size_t)(ns + 1));
+    for (int i = 0; i < ns; i++) {
+      lvl_kp[l][4 * i] = sel[3 * i] + (float)minBorderX;
+      lvl_kp[l][4 * i + 1] = sel[3 * i + 1] + (float)minBorderY;
+      lvl_kp[l][4 * i + 2] = sel[3 * i + 2];
+    }
+    lvl_n[l] = ns;
+    nkeypoints += ns;
+    free(cand);
+    free(sel);
+  }
+  for (int l = 0; l < nl; l++)
+    for (int i = 0; i < lvl_n[l]; i++)
+      lvl_kp[l][4 * i + 3] = orc_ic_angle(e, levels[l], (size_t)lw[l], lvl_kp[l][4 * i], lvl_kp[l][4 * i + 1]);
+
+  *n_out = nkeypoints;
+  int monoIndex = 0, stereoIndex = nkeypoints - 1;
+  if (nkeypoints <= cap) {
+    for (int l = 0; l < nl; l++) {
+      if (lvl_n[l] == 0) continue;
+      uint8_t *blur = (uint8_t *)malloc((size_t)lw[l] * lh[l]);
+      orc_gaussian_blur7(levels[l], lw[l], lh[l], (size_t)lw[l], blur, (size_t)lw[l]);
+      const int scaledPatchSize = (int)((float)PATCH_SIZE * e->mvScaleFactor[l]); /* :862 */
+      float scale = e->mvScaleFactor[l];
+      for (int i = 0; i < lvl_n[l]; i++) {
+        float x = lvl_kp[l][4 * i], y = lvl_kp[l][4 * i + 1];
+        uint8_t d[32];
+        orc_compute_descriptor(blur, (size_t)lw[l], x, y, lvl_kp[l][4 * i + 3], d);
+        orc_keypoint kp;
+        kp.x = x; kp.y = y;
+        kp.size = (float)scaledPatchSize;
+        kp.angle = lvl_kp[l][4 * i + 3];
+        kp.response = lvl_kp[l][4 * i + 2];
+        kp.octave = l;
+        kp.class_id = -1;
+        if (l != 0) { kp.x *= scale; kp.y *= scale; }
+        int dst;
+        if (kp.x >= (float)lap0 && kp.x <= (float)lap1) dst = stereoIndex--;
+        else dst = monoIndex++;
+        kps[dst] = kp;
+        memcpy(desc + 32 * (size_t)dst, d, 32);
+      }
+      free(blur);
+    }
+  } else {
+    monoIndex = -2; /* capacity too small */
+  }
+  for (int l = 0; l < nl; l++) { free(levels[l]); free(lvl_kp[l]); }
+  return monoIndex;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M1 DescriptorDistance, ORBmatcher.cc:2463-2483                                               */
+/* ------------------------------------------------------------------------------------------ */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    uint32_t v = pa ^ pb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (int)((((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24);
+  }
+  return dist;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* G1 grid, Frame.cc:379-380, 434-465, 744-825                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static int pos_in_grid(const orc_frame *f, float x, float y, int *px, int *py) {
+  *px = (int)roundf((x - f->mnMinX) * f->mfGridElementWidthInv);
+  *py = (int)roundf((y - f->mnMinY) * f->mfGridElementHeightInv);
+  if (*px < 0 || *px >= ORC_GRID_COLS || *py < 0 || *py >= ORC_GRID_ROWS) return 0;
+  return 1;
+}
+
+void orc_frame_init(orc_frame *f, int N, const float *kx, const float *ky, const int32_t *octave, const float *angle,
+                    const uint8_t *desc, const float *uRight, float minX, float maxX, float minY, float maxY,
+                    const float *scaleFactors, int nlevels) {
+  memset(f, 0, sizeof(*f));
+  f->N = N; f->kx = kx; f->ky = ky; f->octave = octave; f->angle = angle; f->desc = desc; f->uRight = uRight;
+  f->mnMinX = minX; f->mnMaxX = maxX; f->mnMinY = minY; f->mnMaxY = maxY;
+  f->mfGridElementWidthInv = (float)ORC_GRID_COLS / (maxX - minX);
+  f->mfGridElementHeightInv = (float)ORC_GRID_ROWS / (maxY - minY);
+  f->mvScaleFactors = scaleFactors; f->nlevels = nlevels;
+  const int nc = ORC_GRID_COLS * ORC_GRID_ROWS;
+  int *cnt = (int *)calloc((size_t)nc + 1, sizeof(int));
+  int *cellof = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  for (int i = 0; i < N; i++) {
+    int px, py;
+    if (pos_in_grid(f, kx[i], ky[i], &px, &py)) { cellof[i] = px * ORC_GRID_ROWS + py; cnt[cellof[i]]++; }
+    else cellof[i] = -1;
+  }
+  f->cell_start[0] = 0;
+  for (int c = 0; c < nc; c++) f->cell_start[c + 1] = f->cell_start[c] + cnt[c];
+  f->cell_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  memset(cnt, 0, sizeof(int) * (size_t)nc);
+  for (int i = 0; i < N; i++)
+    if (cellof[i] >= 0) f->cell_idx[f->cell_start[cellof[i]] + cnt[cellof[i]]++] = i;
+  free(cnt);
+  free(cellof);
+}
+
+void orc_frame_free(orc_frame *f) { free(f->cell_idx); f->cell_idx = NULL; }
+
+int orc_get_features_in_area(const orc_frame *f, float x, float y, float r, int minLevel, int maxLevel, int32_t *out) {
+  int n = 0;
+  float factorX = r, factorY = r;
+  int nMinCellX = (int)floorf((x - f->mnMinX - factorX) * f->mfGridElementWidthInv);
+  if (nMinCellX < 0) nMinCellX = 0;
+  if (nMinCellX >= ORC_GRID_COLS) return 0;
+  int nMaxCellX = (int)ceilf((x - f->mnMinX + factorX) * f->mfGridElementWidthInv);
+  if (nMaxCellX > ORC_GRID_COLS - 1) nMaxCellX = ORC_GRID_COLS - 1;
+  if (nMaxCellX < 0) return 0;
+  int nMinCellY = (int)floorf((y - f->mnMinY - factorY) * f->mfGridElementHeightInv);
+  if (nMinCellY < 0) nMinCellY = 0;
+  if (nMinCellY >= ORC_GRID_ROWS) return 0;
+  int nMaxCellY = (int)ceilf((y - f->mnMinY + factorY) * f->mfGridElementHeightInv);
+  if (nMaxCellY > ORC_GRID_ROWS - 1) nMaxCellY = ORC_GRID_ROWS - 1;
+  if (nMaxCellY < 0) return 0;
+  const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      int c = ix * ORC_GRID_ROWS + iy;
+      for (int j = f->cell_start[c]; j < f->cell_start[c + 1]; j++) {
+        int idx = f->cell_idx[j];
+        if (bCheckLevels) {
+          if (f->octave[idx] < minLevel) continue;
+          if (maxLevel >= 0)
+            if (f->octave[idx] > maxLevel) continue;
+        }
+        const float distx = f->kx[idx] - x;
+        const float disty = f->ky[idx] - y;
+        if (fabsf(distx) < factorX && fabsf(disty) < factorY) out[n++] = idx;
+      }
+    }
+  }
+  return n;
+}
+
+float orc_radius_by_viewing_cos(float viewCos) {
+  if ((double)viewCos > 0.998) return 2.5f; /* float compared with a double literal, ORBmatcher.cc:218 */
+  else return 4.0f;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M2, ORBmatcher.cc:44-143 (mono / rectified-stereo half; Nleft == -1)                         */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_projection_mp(orc_frame *f, int nq, const uint8_t *in_view, const uint8_t *qdesc, const float *projX,
+                                const float *projY, const float *projXR, const float *viewCos, const int32_t *level,
+                                const uint8_t *qobs, float th, float nnratio, int32_t *slot, uint8_t *slot_obs,
+                                int32_t *match_of_query) {
+  int nmatches = 0;
+  const int bFactor = ((double)th != 1.0);
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->N > 0 ? f->N : 1));
+  for (int q = 0; q < nq; q++) {
+    if (match_of_query) match_of_query[q] = -1;
+    if (!in_view[q]) continue;
+    const int nPredictedLevel = level[q];
+    float r = orc_radius_by_viewing_cos(viewCos[q]);
+    if (bFactor) r *= th;
+    int nv = orc_get_features_in_area(f, projX[q], projY[q], r * f->mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
+                                      nPredictedLevel, vIndices);
+    if (nv == 0) continue;
+    const uint8_t *MPdescriptor = qdesc + 32 * (size_t)q;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < nv; k++) {
+      const int idx = vIndices[k];
+      if (slot[idx] >= 0)
+        if (slot_obs[idx]) continue;
+      if (f->uRight && f->uRight[idx] > 0) {
+        const float er = fabsf(projXR[q] - f->uRight[idx]);
+        if (er > r * f->mvScaleFactors[nPredictedLevel]) continue;
+      }
+      const int dist = orc_descriptor_distance(MPdescriptor, f->desc + 32 * (size_t)idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist;
+        bestLevel2 = bestLevel; bestLevel = f->octave[idx];
+        bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = f->octave[idx];
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= 100 /* TH_HIGH */) {
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      slot[bestIdx] = q;
+      slot_obs[bestIdx] = qobs ? qobs[q] : 1;
+      if (match_of_query) match_of_query[q] = bestIdx;
+      nmatches++;
+    }
+  }
+  free(vIndices);
+  return nmatches;
+}
+
+int orc_search_by_projection_win(orc_frame *f, int nq, const uint8_t *in_view, const uint8_t *qdesc, const float *u,
+                                 const float *v, const float *radius, const int32_t *minLevel, const int32_t *maxLevel,
+                                 const uint8_t *qobs, float nnratio, int th_high, int mode_second, int32_t *slot,
+                                 uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist_out) {
+  int nmatches = 0;
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->N > 0 ? f->N : 1));
+  for (int q = 0; q < nq; q++) {
+    if (match_of_query) match_of_query[q] = -1;
+    if (best_dist_out) best_dist_out[q] = 256;
+    if (in_view && !in_view[q]) continue;
+    int nv = orc_get_features_in_area(f, u[q], v[q], radius[q], minLevel[q], maxLevel[q], vIndices);
+    if (nv == 0) continue;
+    const uint8_t *d = qdesc + 32 * (size_t)q;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < nv; k++) {
+      const int idx = vIndices[k];
+      if (slot[idx] >= 0)
+        if (slot_obs[idx]) continue;
+      const int dist = orc_descriptor_distance(d, f->desc + 32 * (size_t)idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist;
+        bestLevel2 = bestLevel; bestLevel = f->octave[idx];
+        bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = f->octave[idx];
+        bestDist2 = dist;
+      }
+    }
+    if (best_dist_out) best_dist_out[q] = bestDist;
+    if (bestDist <= th_high) {
+      if (mode_second && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+      slot[bestIdx] = q;
+      slot_obs[bestIdx] = qobs ? qobs[q] : 1;
+      if (match_of_query) match_of_query[q] = bestIdx;
+      nmatches++;
+    }
+  }
+  free(vIndices);
+  return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* C1 / C2 projections                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+void orc_project(int type, const float *p, float X, float Y, float Z, float *u, float *v) {
+  if (type == 0) { /* Pinhole.cpp:46-49 */
+    *u = p[0] * X / Z + p[2];
+    *v = p[1] * Y / Z + p[3];
+  } else { /* KannalaBrandt8.cpp:29-45 */
+    const float x2_plus_y2 = X * X + Y * Y;
+    const float theta = atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = atan2f(Y, X);
+    const float theta2 = theta * theta;
+    const float theta3 = theta * theta2;
+    const float theta5 = theta3 * theta2;
+    const float theta7 = theta5 * theta2;
+    const float theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    /* un-suffixed cos/sin on a float in a TU without `using namespace std` -> ::cos(double)
+     * (hard part 7); the products are then evaluated in double. */
+    *u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
+    *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M7 ComputeThreeMaxima, ORBmatcher.cc:2416-2458                                               */
+/* ------------------------------------------------------------------------------------------ */
+void orc_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  *ind1 = *ind2 = *ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = histo[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+    else if (s > max3) { max3 = s; *ind3 = i; }
+  }
+  if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+  else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M3, ORBmatcher.cc:2027-2289 (Nleft == -1 path)                                               */
+/* cv::Mat products restated per SURVEY.md A.8: the 3x3*3x1 `A*B+C` MatExpr is one cv::gemm whose
+ * small-matrix float path forms a0*b0+a1*b1+a2*b2 in float then adds C; the transposed,
+ * alpha=-1 product goes through the generic path that accumulates in double. [OPENCV-UNVERIFIED] */
+/* ------------------------------------------------------------------------------------------ */
+static void mat3_mul_add(const float *R /*row-major 3x3, row stride rs*/, int rs, const float *x, const float *t, float *out) {
+  for (int i = 0; i < 3; i++) {
+    float t0 = R[i * rs + 0] * x[0] + R[i * rs + 1] * x[1] + R[i * rs + 2] * x[2];
+    out[i] = (float)((double)t0 * 1.0 + (double)t[i] * 1.0);
+  }
+}
+
+int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
+                                const int32_t *lastOctave, const float *lastAngle, const uint8_t *qobs, const float *Tcw,
+                                const float *Tlw, int camType, const float *camParams, float mb, float mbf, float th,
+                                int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs) {
+  int nmatches = 0;
+  const int HISTO_LENGTH = 30;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(nLast + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+  float tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+  /* twc = -Rcw.t()*tcw : generic gemm path, double accumulation, alpha = -1 */
+  float twc[3];
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)tcw[k];
+    twc[i] = (float)(s * -1.0);
+  }
+  float tlc[3];
+  mat3_mul_add(Tlw, 4, twc, tlw, tlc);
+  const int bForward = tlc[2] > mb && !bMono;
+  const int bBackward = -tlc[2] > mb && !bMono;
+  int32_t *vIndices2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur->N > 0 ? cur->N : 1));
+  for (int i = 0; i < nLast; i++) {
+    if (!has_mp[i]) continue;
+    float x3Dc[3];
+    mat3_mul_add(Tcw, 4, Xw + 3 * i, tcw, x3Dc);
+    const float invzc = (float)(1.0 / (double)x3Dc[2]); /* `1.0/x3Dc.at<float>(2)` is double, stored to float */
+    if (invzc < 0) continue;
+    float uvx, uvy;
+    orc_project(camType, camParams, x3Dc[0], x3Dc[1], x3Dc[2], &uvx, &uvy);
+    if (uvx < cur->mnMinX || uvx > cur->mnMaxX) continue;
+    if (uvy < cur->mnMinY || uvy > cur->mnMaxY) continue;
+    int nLastOctave = lastOctave[i];
+    float radius = th * cur->mvScaleFactors[nLastOctave];
+    int nv;
+    if (bForward) nv = orc_get_features_in_area(cur, uvx, uvy, radius, nLastOctave, -1, vIndices2);
+    else if (bBackward) nv = orc_get_features_in_area(cur, uvx, uvy, radius, 0, nLastOctave, vIndices2);
+    else nv = orc_get_features_in_area(cur, uvx, uvy, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    if (nv == 0) continue;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int k = 0; k < nv; k++) {
+      const int i2 = vIndices2[k];
+      if (slot[i2] >= 0)
+        if (slot_obs[i2]) continue;
+      if (cur->uRight && cur->uRight[i2] > 0) {
+        const float ur = uvx - mbf * invzc;
+        const float er = fabsf(ur - cur->uRight[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = orc_descriptor_distance(dMP, cur->desc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= 100 /* TH_HIGH */) {
+      slot[bestIdx2] = i;
+      slot_obs[bestIdx2] = qobs ? qobs[i] : 1;
+      nmatches++;
+      if (checkOri) {
+        float rot = lastAngle[i] - cur->angle[bestIdx2];
+        if ((double)rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin][rotN[bin]++] = bestIdx2;
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (int j = 0; j < rotN[i]; j++) {
+          slot[rotHist[i][j]] = -1;
+          slot_obs[rotHist[i][j]] = 0;
+          nmatches--;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  free(vIndices2);
+  return nmatches;
+}

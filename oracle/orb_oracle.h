@@ -1,0 +1,165 @@
+/*
+ * orb_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the reference's ORB front end:
+ *   /root/reference/src/ORBextractor.cc  (extractor, X0..X9 of SURVEY.md section 8a)
+ *   /root/reference/src/ORBmatcher.cc    (M1, M2, M3, M4, M7)
+ *   /root/reference/src/Frame.cc         (G1 grid: AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea)
+ *   /root/reference/src/CameraModels/{Pinhole,KannalaBrandt8}.cpp (C1, C2)
+ * plus the OpenCV 3.4.x primitives those files call (resize, FAST, GaussianBlur,
+ * fastAtan2, cvRound), restated from their published algorithms because OpenCV is an
+ * external, un-vendored dependency of the reference (CMakeLists.txt:43-56).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this
+ * path, and neither it nor OpenCV can be built in this image, so this restatement is
+ * the oracle of record (see DESIGN.md "Oracle").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The shipped library (liborbhip.so) never links, loads or calls anything in oracle/.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint layout, 28 bytes. */
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orc_keypoint;
+
+#define ORC_MAX_LEVELS 16
+
+/* ORBextractor constructor state, ORBextractor.cc:408-468. */
+typedef struct {
+  int nfeatures, nlevels, iniThFAST, minThFAST;
+  double scaleFactor;
+  float mvScaleFactor[ORC_MAX_LEVELS], mvInvScaleFactor[ORC_MAX_LEVELS];
+  float mvLevelSigma2[ORC_MAX_LEVELS], mvInvLevelSigma2[ORC_MAX_LEVELS];
+  int mnFeaturesPerLevel[ORC_MAX_LEVELS];
+  int umax[16];
+} orc_extractor;
+
+void orc_extractor_init(orc_extractor *e, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh);
+
+/* Level geometry, ORBextractor.cc:1192-1193. */
+void orc_level_size(const orc_extractor *e, int level, int cols, int rows, int *lcols, int *lrows);
+
+/* --- OpenCV primitives ------------------------------------ */
+int orc_cvRound(double v);
+/* cv::resize INTER_LINEAR 8UC1 (A.3). */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, size_t sstride, uint8_t *dst, int dw, int dh, size_t dstride);
+/* cv::GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101 8UC1 (A.5). src and dst may not alias. */
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride);
+void orc_gauss7_kernel(int k[7]);
+/* cv::FAST(img, kps, threshold, true) type 9_16 (A.1). Returns number of keypoints written
+ * (x, y, score triplets, raster order); cap = capacity in keypoints. */
+int orc_fast9_16(const uint8_t *img, int w, int h, size_t stride, int threshold, int *xys, int cap);
+/* FAST corner score for one pixel (cornerScore<16>), for unit tests. */
+int orc_fast_corner_score(const uint8_t *p, size_t stride, int threshold);
+/* cv::fastAtan2 (A.6). */
+float orc_fast_atan2(float y, float x);
+/* cv::copyMakeBorder BORDER_REFLECT_101 (A.2). */
+void orc_copy_make_border101(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, int border, size_t dstride);
+
+/* --- extractor stages ------------------------------------------------------------- */
+/* IC_Angle, ORBextractor.cc:75-102. img points at the level image origin. */
+float orc_ic_angle(const orc_extractor *e, const uint8_t *img, size_t stride, float ptx, float pty);
+/* computeOrbDescriptor, ORBextractor.cc:106-145. */
+void orc_compute_descriptor(const uint8_t *blurred, size_t stride, float ptx, float pty, float angle_deg, uint8_t desc[32]);
+
+/* Candidate generation of ComputeKeyPointsOctTree for one level (ORBextractor.cc:771-854):
+ * returns count; out[i] = (x, y, response) relative to (minBorderX, minBorderY). */
+int orc_level_candidates(const orc_extractor *e, const uint8_t *img, int w, int h, size_t stride, float *xyr, int cap);
+/* DistributeOctTree, ORBextractor.cc:537-761. in/out are (x,y,response) triplets; returns count. */
+int orc_distribute_octtree(const float *xyr, int n, int minX, int maxX, int minY, int maxY, int N, float *out, int cap);
+
+/* Whole pyramid into caller-provided buffers: levels[l] must hold lrows*lcols bytes (tight stride). */
+void orc_compute_pyramid(const orc_extractor *e, const uint8_t *img, int cols, int rows, size_t stride, uint8_t **levels);
+
+/* ORBextractor::operator(), ORBextractor.cc:1071-1184.
+ * Returns monoIndex, or -1 for an empty image. *n_out = number of keypoints. */
+int orc_extract(const orc_extractor *e, const uint8_t *img, int rows, int cols, size_t stride, int lap0, int lap1,
+                orc_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* glibc sinf/cosf as called by the reference (ORBextractor.cc:111), exported so tests can compare
+ * the product's replica against the host libm. */
+float orc_libm_cosf(float x);
+float orc_libm_sinf(float x);
+
+/* --- matcher ---------------------------------------------------------------------- */
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483. */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+#define ORC_GRID_COLS 64 /* Frame.h:38 */
+#define ORC_GRID_ROWS 48 /* Frame.h:39 */
+
+/* The slice of Frame that the matcher reads (mono / rectified-stereo; Nleft == -1). */
+typedef struct {
+  int N;
+  const float *kx, *ky;       /* mvKeysUn[i].pt */
+  const int32_t *octave;      /* mvKeysUn[i].octave */
+  const float *angle;         /* mvKeysUn[i].angle */
+  const uint8_t *desc;        /* mDescriptors, N x 32 */
+  const float *uRight;        /* mvuRight or NULL (treated as all -1) */
+  float mnMinX, mnMaxX, mnMinY, mnMaxY;
+  float mfGridElementWidthInv, mfGridElementHeightInv;
+  const float *mvScaleFactors;
+  int nlevels;
+  /* grid: CSR in (ix, iy) cell-major order = mGrid[ix][iy] vectors */
+  int32_t cell_start[ORC_GRID_COLS * ORC_GRID_ROWS + 1];
+  int32_t *cell_idx; /* N entries, owned */
+} orc_frame;
+
+/* Frame.cc:379-380 + AssignFeaturesToGrid :434-465 + PosInGrid :815-825. */
+void orc_frame_init(orc_frame *f, int N, const float *kx, const float *ky, const int32_t *octave, const float *angle,
+                    const uint8_t *desc, const float *uRight, float minX, float maxX, float minY, float maxY,
+                    const float *scaleFactors, int nlevels);
+void orc_frame_free(orc_frame *f);
+/* Frame::GetFeaturesInArea (bRight=false), Frame.cc:744-813. Returns count. */
+int orc_get_features_in_area(const orc_frame *f, float x, float y, float r, int minLevel, int maxLevel, int32_t *out);
+
+/* Generic projection search core shared by M2/M3/M4 restatements.
+ * slot[i]      : query id occupying keypoint i, or -1 (mvpMapPoints[i] == NULL)
+ * slot_obs[i]  : 1 if that occupant has Observations()>0 */
+/* M2: SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) ORBmatcher.cc:44-214 (left/mono half).
+ * Per query q: in_view[q] (mbTrackInView && !isBad && far-point test), desc, projX/projY, projXR, viewCos,
+ * level (mnTrackScaleLevel), obs[q] = Observations()>0 of that map point. Returns nmatches. */
+int orc_search_by_projection_mp(orc_frame *f, int nq, const uint8_t *in_view, const uint8_t *qdesc,
+                                const float *projX, const float *projY, const float *projXR,
+                                const float *viewCos, const int32_t *level, const uint8_t *qobs,
+                                float th, float nnratio, int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query);
+
+/* Generic windowed variant used for the BASELINE config-3 stress case and by tests: per-query radius and
+ * level window given explicitly (GetFeaturesInArea arguments), otherwise M2 semantics. */
+int orc_search_by_projection_win(orc_frame *f, int nq, const uint8_t *in_view, const uint8_t *qdesc,
+                                 const float *u, const float *v, const float *radius, const int32_t *minLevel,
+                                 const int32_t *maxLevel, const uint8_t *qobs, float nnratio, int th_high,
+                                 int mode_second, int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query,
+                                 int32_t *best_dist_out);
+
+/* Camera models. type 0 = Pinhole (Pinhole.cpp:46-49), 1 = KannalaBrandt8 (KannalaBrandt8.cpp:29-45). */
+void orc_project(int type, const float *params, float X, float Y, float Z, float *u, float *v);
+
+/* M3: SearchByProjection(Frame &Cur, const Frame &Last, th, bMono), ORBmatcher.cc:2027-2289, Nleft==-1 path.
+ * Last-frame side flattened: for i in 0..nLast: has_mp[i] (mvpMapPoints[i] && !mvbOutlier[i]), world pos Xw[3i..],
+ * descriptor of the map point, last octave, last angle, obs flag. Tcw row-major 4x4 (only 3x4 used).
+ * Returns nmatches (after rotation-histogram pruning when checkOri). */
+int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
+                                const int32_t *lastOctave, const float *lastAngle, const uint8_t *qobs,
+                                const float *Tcw, const float *Tlw, int camType, const float *camParams, float mb, float mbf,
+                                float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
+
+/* M7: ComputeThreeMaxima, ORBmatcher.cc:2416-2458, on bin sizes. */
+void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
+/* RadiusByViewingCos, ORBmatcher.cc:216-222. */
+float orc_radius_by_viewing_cos(float viewCos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
