@@ -1,0 +1,391 @@
+"""orb-frontend-mi355x: ORB-SLAM3's per-frame feature front end on MI355X.
+
+Host-side mirror (Python, ctypes) of the C ABI in include/orbhip.h, keeping the reference's names:
+`ORBextractor` (include/ORBextractor.h:43-109), `ORBmatcher` (include/ORBmatcher.h:35-108).  The C++ drop-in
+classes with the reference's exact signatures live in csrc/adapter/.  This module is what tests/ and bench.py
+drive; it contains no compute of its own and no CPU fallback: if liborbhip.so is missing or no HIP device is
+usable, construction raises.
+
+The package name starts with a digit (it is fixed by the project layout), so import it with
+    importlib.import_module("3_orb_slam3_selfnote_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liborbhip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+E_EMPTY, E_ARG, E_HIP, E_CAP = -1, -2, -3, -4
+
+# every symbol include/orbhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
+    "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
+    "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
+    "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
+    "orbx_ref_cosf", "orbx_ref_sinf",
+    "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
+    "orbm_search_by_projection_batch_device", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms",
+]
+
+
+class FrameStruct(C.Structure):  # orbm_frame_t
+    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+class QueryStruct(C.Structure):  # orbm_queries_t
+    _fields_ = [("nq", C.c_int32), ("descriptors", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p), ("u_r", C.c_void_p),
+                ("flags", C.c_void_p)]
+
+
+_lib = None
+
+
+def load(build_if_needed=True):
+    """dlopen liborbhip.so (building it first when the sources are newer).  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("liborbhip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbx_create.restype = vp
+    L.orbx_create.argtypes = [i32, f32, i32, i32, i32, i32]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_last_error.argtypes = [vp]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f32
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_get_features_per_level.argtypes = [vp, vp]
+    L.orbx_configure.argtypes = [vp, i32, i32, i32]
+    L.orbx_max_keypoints.argtypes = [vp]
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, vp, i32, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, sz, sz, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.orbx_level_info.argtypes = [vp, i32, vp, vp]
+    L.orbx_download_level.argtypes = [vp, i32, i32, i32, vp, sz]
+    L.orbx_download_blurred_level.argtypes = [vp, i32, i32, vp, sz]
+    L.orbx_download_candidates.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_download_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
+    L.orbx_ref_cosf.restype = f32
+    L.orbx_ref_cosf.argtypes = [f32]
+    L.orbx_ref_sinf.restype = f32
+    L.orbx_ref_sinf.argtypes = [f32]
+    L.orbm_create.restype = vp
+    L.orbm_create.argtypes = [i32]
+    L.orbm_destroy.argtypes = [vp]
+    L.orbm_last_error.restype = C.c_char_p
+    L.orbm_last_error.argtypes = [vp]
+    L.orbm_descriptor_distance.argtypes = [vp, vp]
+    L.orbm_search_by_projection.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]
+    L.orbm_search_by_projection_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, f32, i32, i32,
+                                                         vp, vp, vp, vp, vp, vp]
+    L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.orbm_three_maxima.argtypes = [vp, i32, vp, vp, vp]
+    L.orbm_radius_by_viewing_cos.restype = f32
+    L.orbm_radius_by_viewing_cos.argtypes = [f32]
+    L.orbm_project.argtypes = [i32, vp, f32, f32, f32, vp, vp]
+    L.orbm_set_profiling.argtypes = [vp, i32]
+    L.orbm_get_last_ms.restype = f32
+    L.orbm_get_last_ms.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbError(RuntimeError):
+    pass
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor (ORBextractor.h:43-109) on one MI355X.
+
+    __call__(image, mask, vLappingArea) mirrors operator() (ORBextractor.cc:1071-1184) and returns
+    (monoIndex, keypoints[KP_DTYPE], descriptors[n,32])."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0):
+        self.L = load()
+        self.h = self.L.orbx_create(int(nfeatures), C.c_float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST), int(device))
+        if not self.h:
+            raise OrbError("orbx_create failed: no usable HIP device %d or bad parameters (no CPU fallback)" % device)
+        self.nlevels = int(nlevels)
+        self.nfeatures = int(nfeatures)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc == E_HIP:
+            raise OrbError("%s: %s" % (what, self.L.orbx_last_error(self.h).decode()))
+        if rc == E_ARG:
+            raise ValueError("%s: bad argument (%s)" % (what, self.L.orbx_last_error(self.h).decode()))
+        return rc
+
+    # --- getters, ORBextractor.h:61-81 ---
+    def GetLevels(self):
+        return self.L.orbx_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return float(self.L.orbx_get_scale_factor(self.h))
+
+    def _tables(self):
+        t = [np.zeros(self.nlevels, dtype=np.float32) for _ in range(4)]
+        self.L.orbx_get_scale_tables(self.h, *[_p(a) for a in t])
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        a = np.zeros(self.nlevels, dtype=np.int32)
+        self.L.orbx_get_features_per_level(self.h, _p(a))
+        return a.tolist()
+
+    def configure(self, rows, cols, max_batch=1):
+        return self._check(self.L.orbx_configure(self.h, int(rows), int(cols), int(max_batch)), "orbx_configure")
+
+    def max_keypoints(self):
+        return self.L.orbx_max_keypoints(self.h)
+
+    def __call__(self, image, mask=None, vLappingArea=(0, 1000)):
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, dtype=KP_DTYPE), np.zeros((0, 32), dtype=np.uint8)  # ORBextractor.cc:1075-1076
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise ValueError("image must be CV_8UC1 (ORBextractor.cc:1080)")
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        rows, cols = image.shape
+        cap = self.configure(rows, cols, 1)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = self.L.orbx_extract(self.h, _p(image), rows, cols, C.c_size_t(image.strides[0]), int(vLappingArea[0]),
+                                 int(vLappingArea[1]), _p(kps), _p(desc), cap, C.byref(n))
+        if rc == E_EMPTY:
+            return -1, kps[:0], desc[:0]
+        if rc == E_CAP:
+            raise OrbError("keypoint capacity bound violated: %d > %d" % (n.value, cap))
+        self._check(rc, "orbx_extract")
+        return rc, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_device(self, d_images, rows, cols, stride, frame_stride, nframes, d_kps, d_desc, d_counts, cap,
+                             vLappingArea=(0, 1000), stream=None):
+        """All pointers are device addresses (ints).  Asynchronous on `stream` (hipStream_t as int; None = own)."""
+        rc = self.L.orbx_extract_batch_device(self.h, C.c_void_p(d_images), int(rows), int(cols), C.c_size_t(stride),
+                                              C.c_size_t(frame_stride), int(nframes), int(vLappingArea[0]),
+                                              int(vLappingArea[1]), C.c_void_p(d_kps), C.c_void_p(d_desc),
+                                              C.c_void_p(d_counts), int(cap), C.c_void_p(stream) if stream else None)
+        self._check(rc, "orbx_extract_batch_device")
+        if rc < 0:
+            raise OrbError("orbx_extract_batch_device rc=%d" % rc)
+        return rc
+
+    # --- mvImagePyramid (ORBextractor.h:83) and stage taps ---
+    def level_shape(self, level):
+        r, c = C.c_int(), C.c_int()
+        self._check(self.L.orbx_level_info(self.h, level, C.byref(r), C.byref(c)), "orbx_level_info")
+        return r.value, c.value
+
+    def image_pyramid_level(self, level, frame=0, border=0):
+        r, c = self.level_shape(level)
+        out = np.zeros((r + 2 * border, c + 2 * border), dtype=np.uint8)
+        self._check(self.L.orbx_download_level(self.h, frame, level, border, _p(out), C.c_size_t(out.strides[0])), "orbx_download_level")
+        return out
+
+    def blurred_level(self, level, frame=0):
+        r, c = self.level_shape(level)
+        out = np.zeros((r, c), dtype=np.uint8)
+        self._check(self.L.orbx_download_blurred_level(self.h, frame, level, _p(out), C.c_size_t(out.strides[0])), "orbx_download_blurred_level")
+        return out
+
+    def level_candidates(self, level, frame=0):
+        r, c = self.level_shape(level)
+        cap = (r * c) // 4 + 64
+        out = np.zeros((cap, 3), dtype=np.float32)
+        n = self._check(self.L.orbx_download_candidates(self.h, frame, level, _p(out), cap), "orbx_download_candidates")
+        return out[:n].copy()
+
+    def level_keypoints(self, level, frame=0):
+        cap = self.max_keypoints() + 8
+        out = np.zeros((cap, 3), dtype=np.float32)
+        n = self._check(self.L.orbx_download_level_keypoints(self.h, frame, level, _p(out), cap), "orbx_download_level_keypoints")
+        return out[:n].copy()
+
+    def set_profiling(self, on=True):
+        self.L.orbx_set_profiling(self.h, 1 if on else 0)
+
+    def stage_ms(self):
+        ms = np.zeros(5, dtype=np.float32)
+        n = self.L.orbx_get_stage_ms(self.h, _p(ms), 5)
+        return dict(zip(["pyramid", "fast", "octree", "blur", "describe"], ms[:n].tolist()))
+
+
+class FrameView:
+    """The slice of ORB_SLAM3::Frame the projection searches read (Frame.h mvKeysUn, mDescriptors, mvuRight,
+    mnMinX..mnMaxY; Frame.cc:872-899), plus mvpMapPoints as (slot, slot_obs) arrays."""
+
+    def __init__(self, keys_un, descriptors, bounds, u_right=None):
+        self.keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+        self.descriptors = np.ascontiguousarray(descriptors, dtype=np.uint8)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+        self.bounds = tuple(float(b) for b in bounds)  # mnMinX, mnMaxX, mnMinY, mnMaxY
+        self.N = len(self.keys_un)
+        self.slot = np.full(self.N, -1, dtype=np.int32)     # mvpMapPoints[i] as query id, -1 = NULL
+        self.slot_obs = np.zeros(self.N, dtype=np.uint8)    # Observations()>0 of the holder
+
+    def struct(self):
+        return FrameStruct(self.N, _p(self.keys_un), _p(self.descriptors), _p(self.u_right), C.c_float(self.bounds[0]),
+                           C.c_float(self.bounds[1]), C.c_float(self.bounds[2]), C.c_float(self.bounds[3]))
+
+
+class ORBmatcher:
+    """ORB_SLAM3::ORBmatcher (ORBmatcher.h:35-108) -- the projection-search members, on one MI355X."""
+    TH_LOW = 50
+    TH_HIGH = 100
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.L = load()
+        self.m = self.L.orbm_create(int(device))
+        if not self.m:
+            raise OrbError("orbm_create failed: no usable HIP device %d (no CPU fallback)" % device)
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+
+    def close(self):
+        if getattr(self, "m", None):
+            self.L.orbm_destroy(self.m)
+            self.m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc == E_HIP:
+            raise OrbError("%s: %s" % (what, self.L.orbm_last_error(self.m).decode()))
+        if rc == E_ARG:
+            raise ValueError("%s: bad argument (%s)" % (what, self.L.orbm_last_error(self.m).decode()))
+        return rc
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        return load().orbm_descriptor_distance(_p(a), _p(b))
+
+    @staticmethod
+    def RadiusByViewingCos(viewCos):
+        return float(load().orbm_radius_by_viewing_cos(C.c_float(viewCos)))
+
+    @staticmethod
+    def ComputeThreeMaxima(histo_sizes):
+        h = np.ascontiguousarray(histo_sizes, dtype=np.int32)
+        i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
+        load().orbm_three_maxima(_p(h), len(h), C.byref(i1), C.byref(i2), C.byref(i3))
+        return i1.value, i2.value, i3.value
+
+    def search_window(self, frame, qdesc, u, v, radius, min_level, max_level, flags=None, u_r=None, nnratio=None,
+                      th_dist=None, use_second=True):
+        """orbm_search_by_projection: the core shared by the SearchByProjection overloads."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        qdesc, u, v, radius = a(qdesc, np.uint8), a(u, np.float32), a(v, np.float32), a(radius, np.float32)
+        min_level, max_level = a(min_level, np.int32), a(max_level, np.int32)
+        nq = len(u)
+        flags = None if flags is None else a(flags, np.uint8)
+        u_r = None if u_r is None else a(u_r, np.float32)
+        qs = QueryStruct(nq, _p(qdesc), _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(u_r), _p(flags))
+        fs = frame.struct()
+        moq = np.full(nq, -1, dtype=np.int32)
+        bd = np.full(nq, 256, dtype=np.int32)
+        rc = self.L.orbm_search_by_projection(self.m, C.byref(fs), C.byref(qs),
+                                              C.c_float(self.mfNNratio if nnratio is None else nnratio),
+                                              int(self.TH_HIGH if th_dist is None else th_dist), int(bool(use_second)),
+                                              _p(frame.slot), _p(frame.slot_obs), _p(moq), _p(bd))
+        self._check(rc, "orbm_search_by_projection")
+        if rc < 0:
+            raise OrbError("orbm_search_by_projection rc=%d" % rc)
+        return rc, moq, bd
+
+    def SearchByProjection(self, F, mp_in_view, mp_desc, mp_projX, mp_projY, mp_viewCos, mp_level, scale_factors, th=1.0,
+                           mp_obs=None, mp_projXR=None):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th, ...) -- ORBmatcher.cc:44-143 (mono /
+        rectified-stereo half).  MapPoint fields arrive as arrays: mbTrackInView (&& !isBad && far-point test),
+        GetDescriptor(), mTrackProjX/Y, mTrackViewCos, mnTrackScaleLevel, Observations()>0."""
+        sf = np.asarray(scale_factors, dtype=np.float32)
+        lvl = np.asarray(mp_level, dtype=np.int32)
+        vc = np.asarray(mp_viewCos, dtype=np.float32)
+        r = np.where(vc.astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)  # :216-222
+        if float(np.float32(th)) != 1.0:
+            r = (r * np.float32(th)).astype(np.float32)                                                    # :69-70
+        radius = (r * sf[np.clip(lvl, 0, len(sf) - 1)]).astype(np.float32)                               # :73
+        nq = len(lvl)
+        obs = np.ones(nq, np.uint8) if mp_obs is None else np.asarray(mp_obs, dtype=np.uint8)
+        flags = (np.asarray(mp_in_view, dtype=np.uint8) & 1) | ((obs & 1) << 1)
+        return self.search_window(F, mp_desc, mp_projX, mp_projY, radius, lvl - 1, lvl, flags=flags, u_r=mp_projXR,
+                                  nnratio=self.mfNNratio, th_dist=self.TH_HIGH, use_second=True)
+
+    def hamming_matrix(self, q, c):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        c = np.ascontiguousarray(c, dtype=np.uint8)
+        d = np.zeros((len(q), len(c)), dtype=np.uint16)
+        self._check(self.L.orbm_hamming_matrix(self.m, _p(q), len(q), _p(c), len(c), _p(d)), "orbm_hamming_matrix")
+        return d
+
+    def set_profiling(self, on=True):
+        self.L.orbm_set_profiling(self.m, 1 if on else 0)
+
+    def last_ms(self):
+        return float(self.L.orbm_get_last_ms(self.m))
+
+
+def project(cam_type, params, X, Y, Z):
+    """GeometricCamera::project: 0 = Pinhole (Pinhole.cpp:46-49), 1 = KannalaBrandt8 (KannalaBrandt8.cpp:29-45)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    u, v = C.c_float(), C.c_float()
+    load().orbm_project(int(cam_type), _p(params), C.c_float(X), C.c_float(Y), C.c_float(Z), C.byref(u), C.byref(v))
+    return u.value, v.value

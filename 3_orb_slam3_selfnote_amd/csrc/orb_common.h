@@ -1,0 +1,77 @@
+// orb_common.h -- shared host/device structures of liborbhip (not part of the public ABI).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define ORB_EDGE_THRESHOLD 19  // ORBextractor.cc:72
+#define ORB_PATCH_SIZE 31      // ORBextractor.cc:70
+#define ORB_HALF_PATCH 15      // ORBextractor.cc:71
+#define ORB_MIN_BORDER 16      // EDGE_THRESHOLD-3, ORBextractor.cc:771
+#define ORB_DISC_PIXELS 749    // pixels of the radius-15 disc given by umax (ORBextractor.cc:452-467)
+#define ORB_MAXL 16
+
+// FAST cell tile in LDS: interior <= 59x59 (wCell = ceil(width/floor(width/30)) < 60), +3 px ring.
+#define FAST_TILE_PITCH 72
+#define FAST_TILE_ROWS 66
+#define FAST_S_PITCH 64  // score plane incl. 1-px zero ring: <= 61 columns
+
+// Geometry of one pyramid level; filled on the host (orbx_configure), read by every kernel.
+struct LevelGeom {
+  int w, h;          // level image size (ORBextractor.cc:1192-1193)
+  int pitch;         // bytes per row of the level plane in the workspace
+  int bpitch;        // bytes per row of the blurred plane
+  size_t off;        // byte offset of the level plane inside one frame's pyramid block (level 0: unused)
+  size_t boff;       // byte offset of the blurred plane inside one frame's blur block
+  // FAST cell grid (ORBextractor.cc:771-785)
+  int maxBorderX, maxBorderY;
+  int nCols, nRows, wCell, hCell;
+  int cellCap;       // slots per cell = ceil(wCell/2)*ceil(hCell/2): no two 8-neighbours are both strict maxima
+  int cellBase;      // index of this level's first cell in a frame's cell table
+  int slotBase;      // index of this level's first slot in a frame's slot array
+  // octree (ORBextractor.cc:537-761)
+  int N;             // mnFeaturesPerLevel[level]
+  int nIni;          // round(width/height), :541
+  float hX;          // :543
+  int candBase;      // first dense candidate of this level in a frame's candidate arrays
+  int candCap;
+  int kpBase, kpCap; // level keypoint arrays (octree output)
+  float scale;       // mvScaleFactor[level]
+  float kpsize;      // (float)(int)(PATCH_SIZE*scale), :862
+  // resize tables (level >= 1): index into xtab/ytab
+  int xtabBase, ytabBase;
+  // blur tiles
+  int tilesX, tilesY, tileBase;
+};
+
+struct FrameParams {
+  const LevelGeom *geom;  // device, [nlevels]
+  int nlevels;
+  int nframes;
+  int iniTh, minTh;
+  int lap0, lap1;
+  // level 0 = caller's images
+  const uint8_t *img0;
+  size_t img0_stride, img0_frame_stride;
+  // workspace (per-frame strides in elements of the pointed type)
+  uint8_t *pyr;    size_t pyr_fs;
+  uint8_t *blur;   size_t blur_fs;
+  uint32_t *cellCnt; int cell_fs;
+  uint32_t *slots;   size_t slot_fs;
+  uint32_t *cand;    int cand_fs;   // packed (S<<24 | y<<12 | x), detection-rectangle coordinates
+  uint16_t *knode;                  // node id per candidate (same indexing as cand)
+  uint32_t *lkp;     int lkp_fs;    // octree output, packed like cand, list order
+  uint16_t *lrank;                  // bit15 = inside lapping area, bits0..14 = rank among same class in the level
+  int32_t *lcnt;                    // [frame][nlevels][2] = {count, lapped count}
+  int32_t *candCnt;                 // [frame][nlevels] dense candidate count
+  const int2 *xtab, *ytab;          // resize tables {src index, a0 | a1<<16}
+  const int8_t *disc;               // ORB_DISC_PIXELS x (u, v)
+  int totalTiles;                   // blur tiles per frame
+  int totalCells;                   // FAST cells per frame
+  int totalKp;                      // sum of kpCap
+  int octCap;                       // node capacity of the octree kernel
+  // outputs
+  void *out_kps;       // orbx_keypoint_t [nframes][cap]
+  uint8_t *out_desc;   // [nframes][cap][32]
+  int32_t *out_counts; // [nframes][2]
+  int cap;
+};

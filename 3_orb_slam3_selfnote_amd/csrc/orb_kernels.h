@@ -1,0 +1,705 @@
+// orb_kernels.h -- hand-written gfx950 kernels of the ORB extractor (included once, by orbhip.hip).
+//
+// Kernel inventory (roofline per kernel in DESIGN.md):
+//   k_resize    K1  cv::resize INTER_LINEAR 8U, one pyramid level of every frame per launch
+//   k_fast      K2  FAST-9/16 score + per-cell NMS + per-cell threshold fallback, one workgroup per 30-px cell
+//   k_octree    K3  DistributeOctTree, one workgroup per (frame, level), node list in LDS
+//   k_blur      K5  7x7 sigma-2 fixed-point Gaussian, 64x16 tiles staged through LDS
+//   k_describe  K4+K6+K7  IC_Angle + steered BRIEF + lapping-order scatter, one wavefront (64 lanes) per keypoint
+// All arithmetic is integer or non-contracted IEEE fp32/fp64 (hipcc -ffp-contract=off) so results are bit-exact
+// against the CPU restatement the tests use.  No MFMA: this is byte/bit work bound by HBM, LDS and VALU integer rate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "orb_common.h"
+#include "orb_sincos.h"
+
+#define WAVE 64
+
+__constant__ int8_t c_pattern[1024] = {
+#include "../../include/orb_pattern_data.inc"
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+  return p;
+}
+
+__device__ __forceinline__ const uint8_t *level_plane(const FrameParams &P, int frame, int level, int &pitch) {
+  if (level == 0) {
+    pitch = (int)P.img0_stride;
+    return P.img0 + (size_t)frame * P.img0_frame_stride;
+  }
+  pitch = P.geom[level].pitch;
+  return P.pyr + (size_t)frame * P.pyr_fs + P.geom[level].off;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// inclusive scan inside a wavefront
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    uint32_t t = __shfl_up(v, o, WAVE);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of an LDS array a[0..n) in place using all NT threads (blockDim.x == NT, 1-D block).
+// Returns the total.  sw: LDS scratch of NT/64 + 2 words.
+template <int NT>
+__device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = NT / 64;
+  uint32_t carry = 0;
+  for (int base = 0; base < n; base += NT) {
+    int i = base + tid;
+    uint32_t v = i < n ? a[i] : 0u;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) sw[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      uint32_t s = sw[w];
+      if (w < wid) woff += s;
+      tot += s;
+    }
+    if (i < n) a[i] = carry + woff + inc - v;
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: cv::resize INTER_LINEAR 8UC1.  Level `level` of every frame from level-1.
+// Thread = 4 consecutive output pixels (one 32-bit store); block = 64x4 threads = 256x4 output pixels.
+// Tables {sx, a0|a1<<16} / {sy, b0|b1<<16} are built on the host (orbx_configure).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level) {
+  const LevelGeom G = P.geom[level];
+  const LevelGeom Gs = P.geom[level - 1];
+  const int frame = blockIdx.z;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (dy >= G.h || dx0 >= G.w) return;
+  int spitch;
+  const uint8_t *src = level_plane(P, frame, level - 1, spitch);
+  uint8_t *dst = P.pyr + (size_t)frame * P.pyr_fs + G.off + (size_t)dy * G.pitch;
+  const int2 yt = P.ytab[G.ytabBase + dy];
+  int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
+  const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+  const uint8_t *S0 = src + (size_t)sy0 * spitch, *S1 = src + (size_t)sy1 * spitch;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int dx = dx0 + j;
+    if (dx < G.w) {
+      const int2 xt = P.xtab[G.xtabBase + dx];
+      const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+      const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+      const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+      const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+      int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      packed |= (uint32_t)v << (8 * j);
+    }
+  }
+  if (dx0 + 3 < G.w) {
+    *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
+  } else {
+    for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: FAST-9/16 per cell (ORBextractor.cc:787-854 + cv::FAST).
+//
+// Threshold-free formulation.  For a pixel with centre v and circle c_k let
+//   S = max( max_arcs min_k (v - c_k), max_arcs min_k (c_k - v) )   over the 16 arcs of 9 contiguous pixels.
+// Then "corner at threshold t"  <=>  S > t, and cornerScore = S - 1 for every corner, independent of t.
+// A corner survives cv::FAST's 3x3 NMS iff its S is strictly greater than the S of its 8 neighbours inside the
+// same cell (neighbours outside the cell's detection interior count as 0), again independent of t.  So one pass
+// gives the keypoints for iniThFAST and, if that set is empty, for minThFAST (decided per cell, after NMS).
+//
+// One 256-thread workgroup per cell: tile (<=65x65 B) in LDS, score plane in LDS, wave ballots for the
+// "any corner at iniTh" vote and for the raster-order compaction.  Output: per-cell slot list, packed
+// (response<<24 | y<<12 | x) in detection-rectangle coordinates, raster order inside the cell.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pitch FAST_TILE_PITCH */) {
+  constexpr int Pt = FAST_TILE_PITCH;
+  const int v = c[0];
+  int d[16];
+  d[0] = v - c[3 * Pt + 0];   d[1] = v - c[3 * Pt + 1];   d[2] = v - c[2 * Pt + 2];   d[3] = v - c[1 * Pt + 3];
+  d[4] = v - c[3];            d[5] = v - c[-1 * Pt + 3];  d[6] = v - c[-2 * Pt + 2];  d[7] = v - c[-3 * Pt + 1];
+  d[8] = v - c[-3 * Pt];      d[9] = v - c[-3 * Pt - 1];  d[10] = v - c[-2 * Pt - 2]; d[11] = v - c[-1 * Pt - 3];
+  d[12] = v - c[-3];          d[13] = v - c[1 * Pt - 3];  d[14] = v - c[2 * Pt - 2];  d[15] = v - c[3 * Pt - 1];
+  // sliding window min / max of length 9 on the circular sequence by doubling: 2, 4, 8, then +1
+  int mn[16], mx[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+  int mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
+  int A = -255, B = 255;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int m8 = min(mn4[k], mn4[(k + 4) & 15]);
+    int x8 = max(mx4[k], mx4[(k + 4) & 15]);
+    A = max(A, min(m8, d[(k + 8) & 15]));  // bright centre: all of the arc darker by at least A
+    B = min(B, max(x8, d[(k + 8) & 15]));  // dark centre:  -B = largest margin
+  }
+  int S = max(A, -B);
+  return min(max(S, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_fast(FrameParams P) {
+  __shared__ uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
+  __shared__ uint8_t sS[62 * FAST_S_PITCH];
+  __shared__ uint8_t sM[60 * 60];
+  __shared__ uint32_t sCount;
+  __shared__ uint32_t sWave[16 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int cellId = blockIdx.x, frame = blockIdx.y;
+  int level = 0;
+  for (int l = 1; l < P.nlevels; l++)
+    if (cellId >= P.geom[l].cellBase) level = l;
+  const LevelGeom G = P.geom[level];
+  const int c = cellId - G.cellBase;
+  const int ci = c / G.nCols, cj = c - ci * G.nCols;
+  uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cell_fs + cellId;
+  // ORBextractor.cc:787-803
+  const int iniX = ORB_MIN_BORDER + cj * G.wCell, iniY = ORB_MIN_BORDER + ci * G.hCell;
+  const int maxX = min(iniX + G.wCell + 6, G.maxBorderX), maxY = min(iniY + G.hCell + 6, G.maxBorderY);
+  const int tw = maxX - iniX, th = maxY - iniY, cw = tw - 6, ch = th - 6;
+  if (iniX >= G.maxBorderX - 6 || iniY >= G.maxBorderY - 3 || cw <= 0 || ch <= 0) {
+    if (tid == 0) *cellCnt = 0;
+    return;
+  }
+  int pitch;
+  const uint8_t *img = level_plane(P, frame, level, pitch);
+  // tile -> LDS
+  for (int idx = tid; idx < tw * th; idx += 256) {
+    int r = idx / tw, cc = idx - r * tw;
+    sT[r * FAST_TILE_PITCH + cc] = img[(size_t)(iniY + r) * pitch + iniX + cc];
+  }
+  for (int idx = tid; idx < (ch + 2) * FAST_S_PITCH; idx += 256) sS[idx] = 0;
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  const int npx = cw * ch;
+  for (int p = tid; p < npx; p += 256) {
+    int y = p / cw, x = p - y * cw;
+    int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + x + 3]);
+    sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
+  }
+  __syncthreads();
+  // 3x3 strict maximum inside the cell; votes for the iniThFAST set
+  uint32_t myIni = 0;
+  for (int p = tid; p < npx; p += 256) {
+    int y = p / cw, x = p - y * cw;
+    const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
+    int S = s[0];
+    bool keep = S >= 2 && S > s[-1] && S > s[1] && S > s[-FAST_S_PITCH - 1] && S > s[-FAST_S_PITCH] &&
+                S > s[-FAST_S_PITCH + 1] && S > s[FAST_S_PITCH - 1] && S > s[FAST_S_PITCH] && S > s[FAST_S_PITCH + 1];
+    sM[p] = keep ? (uint8_t)S : 0;
+    myIni += (keep && S > P.iniTh) ? 1u : 0u;
+  }
+  unsigned long long anyv = __ballot(myIni != 0);
+  if (lane == 0 && anyv) atomicOr(&sCount, 1u);
+  __syncthreads();
+  const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, ORBextractor.cc:825-828
+  // raster-order compaction: pixel p = k*256 + tid; wave w of iteration k owns pixels [k*256+64w, +64)
+  const int niter = (npx + 255) / 256;
+  for (int k = 0; k < niter; k++) {
+    int p = k * 256 + tid;
+    bool f = p < npx && sM[p] > thr;
+    unsigned long long b = __ballot(f);
+    if (lane == 0) sWave[k * 4 + wid] = (uint32_t)__popcll(b);
+  }
+  __syncthreads();
+  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase + (size_t)c * G.cellCap;
+  uint32_t base = 0;
+  for (int k = 0; k < niter; k++) {
+    int p = k * 256 + tid;
+    bool f = p < npx && sM[p] > thr;
+    unsigned long long b = __ballot(f);
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; w++) woff += sWave[k * 4 + w];
+    if (f) {
+      uint32_t rank = base + woff + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      int y = p / cw, x = p - y * cw;
+      uint32_t X = (uint32_t)(cj * G.wCell + x + 3), Y = (uint32_t)(ci * G.hCell + y + 3);
+      if (rank < (uint32_t)G.cellCap) slots[rank] = ((uint32_t)(sM[p] - 1) << 24) | (Y << 12) | X;
+    }
+    base += sWave[k * 4 + 0] + sWave[k * 4 + 1] + sWave[k * 4 + 2] + sWave[k * 4 + 3];
+  }
+  if (tid == 0) *cellCnt = min(base, (uint32_t)G.cellCap);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3: DistributeOctTree (ORBextractor.cc:479-761), one 256-thread workgroup per (frame, level).
+//
+// Data-parallel restatement (model + proof-by-test in tests/octree_model.py):
+//  * the std::list is an array in list order; a round builds the next array with prefix sums:
+//      new list = [children of the nodes processed this round, in reverse processing order, each as n4,n3,n2,n1]
+//                 ++ [unprocessed nodes in their old order]            (push_front / erase semantics, :619-661)
+//  * keys never move: each candidate carries the list position of its node (knode) and is re-labelled per round;
+//  * full rounds process every node with >1 key in list order (:598-663); once size + 3*nToExpand > N (:671)
+//    rounds process nodes by (size desc, creation order desc) = (size desc, list position asc) and stop at the
+//    first prefix that reaches N nodes (:682-729) -- the cut is found with a scan over the ranked child counts;
+//  * the winner of a node is max response, first in vKeys order on ties (:745-757) = smallest dense index,
+//    taken with a 64-bit LDS atomicMax over (response, ~index).
+// Candidates are first compacted from the per-cell slot lists into the reference's vToDistributeKeys order.
+// ------------------------------------------------------------------------------------------------------------
+struct OctNode { short ulx, urx, uly, bry; };
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffScratch) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int CAP = P.octCap;
+  // carve (all offsets multiples of 8)
+  unsigned long long *best = reinterpret_cast<unsigned long long *>(smem);          // aliases chcnt/chpos
+  uint32_t *chcnt = reinterpret_cast<uint32_t *>(smem);                               // 4*CAP
+  int32_t *chpos = reinterpret_cast<int32_t *>(smem + 16 * (size_t)CAP);              // 4*CAP
+  OctNode *nodeA = reinterpret_cast<OctNode *>(smem + 32 * (size_t)CAP);
+  OctNode *nodeB = nodeA + CAP;
+  uint32_t *cntA = reinterpret_cast<uint32_t *>(nodeB + CAP);
+  uint32_t *cntB = cntA + CAP;
+  int32_t *npos = reinterpret_cast<int32_t *>(cntB + CAP);
+  int32_t *rankOf = npos + CAP;
+  uint32_t *incl = reinterpret_cast<uint32_t *>(rankOf + CAP);  // child counts by rank -> inclusive sums
+  uint32_t *sflag = incl + CAP;                                  // unprocessed flags -> exclusive sums
+  uint32_t *sw = sflag + CAP;                                    // scan scratch (NT/64+2)
+  __shared__ int shI[8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = NT / 64;
+  const int level = blockIdx.x, frame = blockIdx.y;
+  const LevelGeom G = P.geom[level];
+  int32_t *lcnt = P.lcnt + ((size_t)frame * P.nlevels + level) * 2;
+  uint32_t *cand = P.cand + (size_t)frame * P.cand_fs + G.candBase;
+  uint16_t *knode = P.knode + (size_t)frame * P.cand_fs + G.candBase;
+
+  // ---- A. compact the per-cell slot lists into vToDistributeKeys order (cells row-major, raster inside) ----
+  const int ncell = G.nCols * G.nRows;
+  const uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cell_fs + G.cellBase;
+  uint32_t *cellOff = cellOffScratch + (size_t)frame * P.cell_fs + G.cellBase;
+  uint32_t carry = 0;
+  for (int base = 0; base < ncell; base += NT) {
+    int i = base + tid;
+    uint32_t v = i < ncell ? cellCnt[i] : 0u;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) sw[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < NW; w++) { uint32_t s = sw[w]; if (w < wid) woff += s; tot += s; }
+    if (i < ncell) cellOff[i] = carry + woff + inc - v;
+    carry += tot;
+    __syncthreads();
+  }
+  const int n = min((int)carry, G.candCap);
+  if (tid == 0) P.candCnt[(size_t)frame * P.nlevels + level] = n;
+  if (n == 0) {
+    if (tid == 0) { lcnt[0] = 0; lcnt[1] = 0; }
+    return;
+  }
+  __syncthreads();  // cellOff visible to the whole workgroup
+  {
+    const uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase;
+    for (int cidx = wid; cidx < ncell; cidx += NW) {
+      uint32_t cnt = cellCnt[cidx], off = cellOff[cidx];
+      for (uint32_t j = lane; j < cnt; j += 64)
+        if (off + j < (uint32_t)n) cand[off + j] = slots[(size_t)cidx * G.cellCap + j];
+    }
+  }
+  __syncthreads();
+
+  // ---- B. root nodes (ORBextractor.cc:541-585) ----
+  const int nIni = G.nIni;
+  const float hX = G.hX;
+  const int Hrect = G.maxBorderY - ORB_MIN_BORDER;
+  for (int i = tid; i < nIni; i += NT) chcnt[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += NT) {
+    uint32_t c = cand[k];
+    int r = (int)((float)(c & 0xfff) / hX);  // vpIniNodes[kp.pt.x/hX], :567
+    r = min(max(r, 0), nIni - 1);
+    knode[k] = (uint16_t)r;
+    atomicAdd(&chcnt[r], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int L = 0;
+    for (int r = 0; r < nIni; r++) {
+      uint32_t cn = chcnt[r];
+      if (cn > 0) {
+        OctNode nd;
+        nd.ulx = (short)(int)(hX * (float)r);
+        nd.urx = (short)(int)(hX * (float)(r + 1));
+        nd.uly = 0;
+        nd.bry = (short)Hrect;
+        nodeA[L] = nd;
+        cntA[L] = cn;
+        chpos[r] = L;
+        L++;
+      }
+    }
+    shI[0] = L;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += NT) knode[k] = (uint16_t)chpos[knode[k]];
+  int L = shI[0];
+  __syncthreads();
+
+  // ---- C. rounds ----
+  const int N = G.N;
+  bool careful = false;
+  OctNode *nodes = nodeA, *nodesN = nodeB;
+  uint32_t *cnts = cntA, *cntsN = cntB;
+  for (int guard = 0; guard < 64; guard++) {
+    const int prevSize = L;
+    for (int i = tid; i < 4 * L; i += NT) chcnt[i] = 0;
+    if (tid == 0) { shI[1] = 0; shI[2] = 0x7fffffff; }
+    __syncthreads();
+    // child key counts of every expandable node
+    for (int k = tid; k < n; k += NT) {
+      int nd = knode[k];
+      if (cnts[nd] > 1) {
+        OctNode o = nodes[nd];
+        uint32_t c = cand[k];
+        int x = c & 0xfff, y = (c >> 12) & 0xfff;
+        int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;  // ceil(/2), :481-482
+        int q = (x < o.ulx + hx ? 0 : 1) + (y < o.uly + hy ? 0 : 2);
+        atomicAdd(&chcnt[nd * 4 + q], 1u);
+      }
+    }
+    __syncthreads();
+    // rank of the expandable nodes in processing order
+    if (!careful) {
+      for (int i = tid; i < L; i += NT) sflag[i] = cnts[i] > 1 ? 1u : 0u;
+      __syncthreads();
+      uint32_t nX = lds_excl_scan<NT>(sflag, L, sw);
+      for (int i = tid; i < L; i += NT) rankOf[i] = cnts[i] > 1 ? (int)sflag[i] : -1;
+      if (tid == 0) shI[3] = (int)nX;
+    } else {
+      uint32_t myX = 0;
+      for (int i = tid; i < L; i += NT) {
+        uint32_t ci = cnts[i];
+        int r = -1;
+        if (ci > 1) {
+          r = 0;
+          for (int j = 0; j < L; j++) {
+            uint32_t cj = cnts[j];
+            r += (cj > 1 && (cj > ci || (cj == ci && j < i))) ? 1 : 0;
+          }
+          myX++;
+        }
+        rankOf[i] = r;
+      }
+      myX = (uint32_t)wave_sum_i32((int)myX);
+      if (lane == 0 && myX) atomicAdd(&shI[1], (int)myX);
+      __syncthreads();
+      if (tid == 0) { shI[3] = shI[1]; shI[1] = 0; }
+    }
+    __syncthreads();
+    const int nX = shI[3];
+    // child counts in rank order -> inclusive sums
+    for (int i = tid; i < L; i += NT) {
+      int r = rankOf[i];
+      if (r >= 0) {
+        uint32_t c = (chcnt[i * 4] > 0) + (chcnt[i * 4 + 1] > 0) + (chcnt[i * 4 + 2] > 0) + (chcnt[i * 4 + 3] > 0);
+        incl[r] = c;
+      }
+    }
+    __syncthreads();
+    lds_excl_scan<NT>(incl, nX, sw);  // exclusive; inclusive = excl + c, recomputed below
+    // cut of a careful round: first rank r with L + incl(r) - (r+1) >= N  (:728)
+    if (careful) {
+      for (int i = tid; i < L; i += NT) {
+        int r = rankOf[i];
+        if (r >= 0) {
+          uint32_t c = (chcnt[i * 4] > 0) + (chcnt[i * 4 + 1] > 0) + (chcnt[i * 4 + 2] > 0) + (chcnt[i * 4 + 3] > 0);
+          int after = L + (int)(incl[r] + c) - (r + 1);
+          if (after >= N) atomicMin(&shI[2], r);
+        }
+      }
+    }
+    __syncthreads();
+    int mstar = nX - 1;
+    if (careful && shI[2] != 0x7fffffff) mstar = shI[2];
+    // Eproc = inclusive sum at mstar; unprocessed flags
+    for (int i = tid; i < L; i += NT) {
+      int r = rankOf[i];
+      bool proc = r >= 0 && r <= mstar;
+      sflag[i] = proc ? 0u : 1u;
+      if (r == mstar && r >= 0) {
+        uint32_t c = (chcnt[i * 4] > 0) + (chcnt[i * 4 + 1] > 0) + (chcnt[i * 4 + 2] > 0) + (chcnt[i * 4 + 3] > 0);
+        shI[4] = (int)(incl[r] + c);
+      }
+    }
+    if (tid == 0 && nX == 0) shI[4] = 0;
+    __syncthreads();
+    const int Eproc = shI[4];
+    uint32_t nUnproc = lds_excl_scan<NT>(sflag, L, sw);
+    const int Lnew = Eproc + (int)nUnproc;
+    // build the next list
+    for (int i = tid; i < L; i += NT) {
+      int r = rankOf[i];
+      OctNode o = nodes[i];
+      if (r >= 0 && r <= mstar) {
+        uint32_t c0 = chcnt[i * 4], c1 = chcnt[i * 4 + 1], c2 = chcnt[i * 4 + 2], c3 = chcnt[i * 4 + 3];
+        uint32_t c = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+        int pos = Eproc - (int)(incl[r] + c);  // block start; inside the block n4,n3,n2,n1
+        int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;
+        int nexp = 0;
+        uint32_t cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int q = 3; q >= 0; q--) {
+          if (cc[q] > 0) {
+            OctNode ch;
+            ch.ulx = (short)((q & 1) ? o.ulx + hx : o.ulx);
+            ch.urx = (short)((q & 1) ? o.urx : o.ulx + hx);
+            ch.uly = (short)((q & 2) ? o.uly + hy : o.uly);
+            ch.bry = (short)((q & 2) ? o.bry : o.uly + hy);
+            if (pos < CAP) { nodesN[pos] = ch; cntsN[pos] = cc[q]; }
+            chpos[i * 4 + q] = pos;
+            nexp += cc[q] > 1 ? 1 : 0;
+            pos++;
+          } else {
+            chpos[i * 4 + q] = -1;
+          }
+        }
+        if (nexp) atomicAdd(&shI[1], nexp);
+        npos[i] = -1;
+      } else {
+        int pos = Eproc + (int)sflag[i];
+        if (pos < CAP) { nodesN[pos] = o; cntsN[pos] = cnts[i]; }
+        npos[i] = pos;
+      }
+    }
+    __syncthreads();
+    // re-label the keys
+    for (int k = tid; k < n; k += NT) {
+      int nd = knode[k];
+      int np = npos[nd];
+      if (np < 0) {
+        OctNode o = nodes[nd];
+        uint32_t c = cand[k];
+        int x = c & 0xfff, y = (c >> 12) & 0xfff;
+        int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;
+        int q = (x < o.ulx + hx ? 0 : 1) + (y < o.uly + hy ? 0 : 2);
+        np = chpos[nd * 4 + q];
+      }
+      knode[k] = (uint16_t)np;
+    }
+    const int nToExpand = shI[1];
+    __syncthreads();
+    { OctNode *t = nodes; nodes = nodesN; nodesN = t; }
+    { uint32_t *t = cnts; cnts = cntsN; cntsN = t; }
+    L = min(Lnew, CAP);
+    if (Lnew >= N || Lnew == prevSize) break;                      // :667, :731
+    if (!careful && Lnew + nToExpand * 3 > N) careful = true;      // :671
+  }
+
+  // ---- D. best key per node, list order out, lapping ranks (ORBextractor.cc:742-758, :1169-1178) ----
+  for (int i = tid; i < L; i += NT) best[i] = 0ull;
+  __syncthreads();
+  for (int k = tid; k < n; k += NT) {
+    uint32_t c = cand[k];
+    unsigned long long key = ((unsigned long long)(c >> 24) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k);
+    atomicMax(&best[knode[k]], key);
+  }
+  __syncthreads();
+  uint32_t *lkp = P.lkp + (size_t)frame * P.lkp_fs + G.kpBase;
+  uint16_t *lrank = P.lrank + (size_t)frame * P.lkp_fs + G.kpBase;
+  const int Lout = min(L, G.kpCap);
+  for (int i = tid; i < Lout; i += NT) {
+    uint32_t k = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
+    uint32_t c = cand[k];
+    lkp[i] = c;
+    float xs = (float)((int)(c & 0xfff) + ORB_MIN_BORDER);
+    if (level != 0) xs = xs * G.scale;  // keypoint->pt *= scale, :1164-1166
+    bool lap = xs >= (float)P.lap0 && xs <= (float)P.lap1;
+    sflag[i] = lap ? 1u : 0u;
+  }
+  __syncthreads();
+  // sflag was read as packed flags; keep a copy of the flag in incl before the scan overwrites it
+  for (int i = tid; i < Lout; i += NT) incl[i] = sflag[i];
+  __syncthreads();
+  uint32_t nLap = lds_excl_scan<NT>(sflag, Lout, sw);
+  for (int i = tid; i < Lout; i += NT) {
+    uint32_t f = incl[i];
+    uint32_t rank = f ? sflag[i] : (uint32_t)i - sflag[i];
+    lrank[i] = (uint16_t)((f << 15) | (rank & 0x7fff));
+  }
+  if (tid == 0) { lcnt[0] = Lout; lcnt[1] = (int)nLap; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5: cv::GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101, 8U fixed point: taps {18,34,49,55,49,34,18},
+// row sums exact in 16 bits, (sum + 32768) >> 16 after the column pass.  64x16 output tile per workgroup.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur(FrameParams P) {
+  __shared__ uint8_t sIn[22 * 72];
+  __shared__ uint16_t sRow[22 * 64];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, frame = blockIdx.y;
+  int level = 0;
+  for (int l = 1; l < P.nlevels; l++)
+    if (tile >= P.geom[l].tileBase) level = l;
+  const LevelGeom G = P.geom[level];
+  const int t = tile - G.tileBase;
+  const int ty = t / G.tilesX, tx = t - ty * G.tilesX;
+  const int x0 = tx * 64, y0 = ty * 16;
+  int pitch;
+  const uint8_t *img = level_plane(P, frame, level, pitch);
+  for (int idx = tid; idx < 22 * 70; idx += 256) {
+    int r = idx / 70, c = idx - r * 70;
+    int yy = reflect101(y0 + r - 3, G.h), xx = reflect101(x0 + c - 3, G.w);
+    sIn[r * 72 + c] = img[(size_t)yy * pitch + xx];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 22 * 64; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    const uint8_t *s = &sIn[r * 72 + c];
+    uint32_t v = 18u * (s[0] + s[6]) + 34u * (s[1] + s[5]) + 49u * (s[2] + s[4]) + 55u * s[3];
+    sRow[idx] = (uint16_t)v;
+  }
+  __syncthreads();
+  uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff;
+  for (int idx = tid; idx < 16 * 64; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    const uint16_t *s = &sRow[r * 64 + c];
+    uint32_t v = 18u * ((uint32_t)s[0] + s[6 * 64]) + 34u * ((uint32_t)s[64] + s[5 * 64]) +
+                 49u * ((uint32_t)s[2 * 64] + s[4 * 64]) + 55u * (uint32_t)s[3 * 64];
+    v = (v + 32768u) >> 16;
+    v = v > 255u ? 255u : v;
+    if (x0 + c < G.w && y0 + r < G.h) out[(size_t)(y0 + r) * G.bpitch + x0 + c] = (uint8_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4+K6+K7: IC_Angle (ORBextractor.cc:75-102), computeOrbDescriptor (:106-145) and the lapping-order scatter
+// (:1159-1180).  One wavefront per keypoint: 749-pixel disc split over 64 lanes and reduced with shuffles;
+// 256 binary tests = 4 rounds of 64 lanes, each round packed with one 64-bit ballot (= 8 descriptor bytes).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, SURVEY.md A.6
+  const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+struct KpOut { float x, y, size, angle, response; int32_t octave, class_id; };
+
+__global__ __launch_bounds__(256) void k_describe(FrameParams P) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int frame = blockIdx.y;
+  if (j >= P.totalKp) return;
+  int level = 0;
+  for (int l = 1; l < P.nlevels; l++)
+    if (j >= P.geom[l].kpBase) level = l;
+  const LevelGeom G = P.geom[level];
+  const int i = j - G.kpBase;
+  const int32_t *lc = P.lcnt + (size_t)frame * P.nlevels * 2;
+  if (i >= lc[level * 2]) return;
+  int nTot = 0, lapBefore = 0, monoBefore = 0;
+  for (int l = 0; l < P.nlevels; l++) {
+    int c = lc[l * 2], lp = lc[l * 2 + 1];
+    nTot += c;
+    if (l < level) { lapBefore += lp; monoBefore += c - lp; }
+  }
+  const uint32_t packed = P.lkp[(size_t)frame * P.lkp_fs + G.kpBase + i];
+  const uint32_t rk = P.lrank[(size_t)frame * P.lkp_fs + G.kpBase + i];
+  const int X = (int)(packed & 0xfff) + ORB_MIN_BORDER, Y = (int)((packed >> 12) & 0xfff) + ORB_MIN_BORDER;
+  const int dst = (rk & 0x8000u) ? nTot - 1 - (lapBefore + (int)(rk & 0x7fff)) : monoBefore + (int)(rk & 0x7fff);
+
+  // IC_Angle on the unblurred level
+  int pitch;
+  const uint8_t *img = level_plane(P, frame, level, pitch);
+  const uint8_t *centre = img + (size_t)Y * pitch + X;
+  int m10 = 0, m01 = 0;
+  for (int e = lane; e < ORB_DISC_PIXELS; e += 64) {
+    int u = P.disc[2 * e], v = P.disc[2 * e + 1];
+    int val = centre[v * pitch + u];
+    m10 += u * val;
+    m01 += v * val;
+  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // steered BRIEF on the blurred level
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float arad = angle * factorPI;
+  const float a = orbsc::ref_cosf(arad), b = orbsc::ref_sinf(arad);
+  const uint8_t *bc = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)Y * G.bpitch + X;
+  const int bp = G.bpitch;
+  unsigned long long bits[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int t = r * 64 + lane;
+    const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
+    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+    const int v0 = bc[__float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b)];
+    const int v1 = bc[__float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b)];
+    bits[r] = __ballot(v0 < v1);
+  }
+  if (dst < P.cap) {
+    uint32_t *dd = reinterpret_cast<uint32_t *>(P.out_desc + ((size_t)frame * P.cap + dst) * 32);
+    if (lane < 8) {
+      unsigned long long w = bits[lane >> 1];
+      dd[lane] = (uint32_t)((lane & 1) ? (w >> 32) : w);
+    }
+    if (lane == 8) {
+      KpOut k;
+      k.x = (float)X;
+      k.y = (float)Y;
+      if (level != 0) { k.x = k.x * G.scale; k.y = k.y * G.scale; }
+      k.size = G.kpsize;
+      k.angle = angle;
+      k.response = (float)(packed >> 24);
+      k.octave = level;
+      k.class_id = -1;
+      reinterpret_cast<KpOut *>(P.out_kps)[(size_t)frame * P.cap + dst] = k;
+    }
+  }
+  if (i == 0 && level == 0 && lane == 0) {
+    // never reached when level 0 is empty; counts are written by k_counts instead
+  }
+}
+
+// per-frame {n, monoIndex} (ORBextractor.cc:1183 returns monoIndex)
+__global__ void k_counts(FrameParams P) {
+  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+  if (frame >= P.nframes) return;
+  const int32_t *lc = P.lcnt + (size_t)frame * P.nlevels * 2;
+  int n = 0, lap = 0;
+  for (int l = 0; l < P.nlevels; l++) { n += lc[l * 2]; lap += lc[l * 2 + 1]; }
+  P.out_counts[frame * 2] = n;
+  P.out_counts[frame * 2 + 1] = n - lap;
+}

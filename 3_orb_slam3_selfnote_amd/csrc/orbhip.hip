@@ -1,0 +1,766 @@
+// orbhip.hip -- liborbhip.so: host side of the C ABI in include/orbhip.h + kernel launches.
+//
+// Build (see 3_orb_slam3_selfnote_amd/build.py):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared orbhip.hip -o liborbhip.so
+// -ffp-contract=off is part of the contract: the reference arithmetic is unfused IEEE.
+//
+// There is deliberately no CPU fallback in this file: every entry point that computes runs HIP kernels and returns
+// ORBX_E_HIP when no device is usable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/orbhip.h"
+#include "orb_kernels.h"
+#include "orb_match_kernels.h"
+
+static_assert(sizeof(orbx_keypoint_t) == 28, "cv::KeyPoint layout");
+static_assert(sizeof(KpOut) == 28, "cv::KeyPoint layout");
+
+namespace {
+
+inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: round-half-even
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) bytes = need;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------------------
+// extractor handle
+// --------------------------------------------------------------------------------------------------------------
+struct orbx_handle {
+  int device = 0;
+  // ORBextractor members (ORBextractor.h:95-109)
+  int nfeatures = 0, nlevels = 0, iniThFAST = 0, minThFAST = 0;
+  double scaleFactor = 0;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+  std::vector<int> mnFeaturesPerLevel;
+  int umax[ORB_HALF_PATCH + 1];
+  // configured geometry
+  int rows = 0, cols = 0, max_batch = 0;
+  std::vector<LevelGeom> geom;
+  size_t pyr_fs = 0, blur_fs = 0, slot_fs = 0;
+  int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
+  int maxKeypoints = 0;
+  // device memory
+  DevBuf d_geom, d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_xtab,
+      d_ytab, d_disc;
+  DevBuf d_img, d_okps, d_odesc, d_ocounts;  // staging for the host entry point
+  hipStream_t stream = nullptr;
+  // last call
+  FrameParams last{};
+  bool have_last = false;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[8] = {};
+  bool ev_ok = false;
+  float stage_ms[5] = {0, 0, 0, 0, 0};
+  bool stage_valid = false;
+  std::string err;
+};
+
+#define XCHECK(h, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return ORBX_E_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+extern "C" {
+
+float orbx_ref_cosf(float x) { return orbsc::ref_cosf(x); }
+float orbx_ref_sinf(float x) { return orbsc::ref_sinf(x); }
+
+orbx_t *orbx_create(int nfeatures, float scaleFactor_, int nlevels, int iniThFAST, int minThFAST, int device) {
+  if (nfeatures < 0 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scaleFactor_ > 1.0f)) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  orbx_handle *h = new orbx_handle();
+  h->device = device;
+  h->nfeatures = nfeatures;
+  h->nlevels = nlevels;
+  h->iniThFAST = std::min(std::max(iniThFAST, 0), 255);  // cv::FAST clamps the threshold to [0,255]
+  h->minThFAST = std::min(std::max(minThFAST, 0), 255);
+  h->scaleFactor = (double)scaleFactor_;  // double member initialised from float, ORBextractor.h:96
+  // ORBextractor.cc:413-429
+  h->mvScaleFactor.resize(nlevels);
+  h->mvLevelSigma2.resize(nlevels);
+  h->mvInvScaleFactor.resize(nlevels);
+  h->mvInvLevelSigma2.resize(nlevels);
+  h->mvScaleFactor[0] = 1.0f;
+  h->mvLevelSigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    h->mvScaleFactor[i] = (float)((double)h->mvScaleFactor[i - 1] * h->scaleFactor);
+    h->mvLevelSigma2[i] = h->mvScaleFactor[i] * h->mvScaleFactor[i];
+  }
+  for (int i = 0; i < nlevels; i++) {
+    h->mvInvScaleFactor[i] = 1.0f / h->mvScaleFactor[i];
+    h->mvInvLevelSigma2[i] = 1.0f / h->mvLevelSigma2[i];
+  }
+  // per-level quotas, ORBextractor.cc:432-444
+  h->mnFeaturesPerLevel.resize(nlevels);
+  const float factor = (float)(1.0 / h->scaleFactor);
+  float nDesired = (float)nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    h->mnFeaturesPerLevel[l] = cv_round(nDesired);
+    sum += h->mnFeaturesPerLevel[l];
+    nDesired *= factor;
+  }
+  h->mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // circular patch row ends, ORBextractor.cc:452-467
+  {
+    int v, v0;
+    const int vmax = (int)floor(ORB_HALF_PATCH * sqrtf(2.f) / 2 + 1);
+    const int vmin = (int)ceil(ORB_HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = ORB_HALF_PATCH * ORB_HALF_PATCH;
+    for (v = 0; v <= ORB_HALF_PATCH; v++) h->umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round(sqrt(hp2 - v * v));
+    for (v = ORB_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+      while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+      h->umax[v] = v0;
+      ++v0;
+    }
+  }
+  std::vector<int8_t> disc;
+  for (int v = -ORB_HALF_PATCH; v <= ORB_HALF_PATCH; v++) {
+    const int d = h->umax[v < 0 ? -v : v];
+    for (int u = -d; u <= d; u++) { disc.push_back((int8_t)u); disc.push_back((int8_t)v); }
+  }
+  if ((int)disc.size() != 2 * ORB_DISC_PIXELS) { delete h; return nullptr; }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
+  if (h->d_disc.reserve(disc.size()) != hipSuccess ||
+      hipMemcpy(h->d_disc.p, disc.data(), disc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void orbx_destroy(orbx_t *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf *bufs[] = {&h->d_geom, &h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
+  for (DevBuf *b : bufs) b->release();
+  if (h->ev_ok)
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char *orbx_last_error(const orbx_t *h) { return h ? h->err.c_str() : "null handle"; }
+int orbx_get_levels(const orbx_t *h) { return h ? h->nlevels : ORBX_E_ARG; }
+float orbx_get_scale_factor(const orbx_t *h) { return h ? (float)h->scaleFactor : 0.f; }
+
+int orbx_get_scale_tables(const orbx_t *h, float *sf, float *isf, float *s2, float *is2) {
+  if (!h) return ORBX_E_ARG;
+  for (int i = 0; i < h->nlevels; i++) {
+    if (sf) sf[i] = h->mvScaleFactor[i];
+    if (isf) isf[i] = h->mvInvScaleFactor[i];
+    if (s2) s2[i] = h->mvLevelSigma2[i];
+    if (is2) is2[i] = h->mvInvLevelSigma2[i];
+  }
+  return h->nlevels;
+}
+
+int orbx_get_features_per_level(const orbx_t *h, int *n) {
+  if (!h || !n) return ORBX_E_ARG;
+  for (int i = 0; i < h->nlevels; i++) n[i] = h->mnFeaturesPerLevel[i];
+  return h->nlevels;
+}
+
+int orbx_max_keypoints(const orbx_t *h) { return h ? h->maxKeypoints : ORBX_E_ARG; }
+
+int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
+  if (!h || rows <= 0 || cols <= 0 || max_batch <= 0) return ORBX_E_ARG;
+  if (rows > 4096 || cols > 4096) { h->err = "image larger than 4096x4096 (12-bit packed coordinates)"; return ORBX_E_ARG; }
+  if (max_batch > 65535) { h->err = "batch larger than 65535"; return ORBX_E_ARG; }
+  if (h->rows == rows && h->cols == cols && h->max_batch >= max_batch) return h->maxKeypoints;
+  XCHECK(h, hipSetDevice(h->device));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  const int nl = h->nlevels;
+  std::vector<LevelGeom> g(nl);
+  std::vector<int2> xtab, ytab;
+  size_t pyr = 0, blur = 0;
+  int cells = 0, slots = 0, kps = 0, tiles = 0, octCap = 8;
+  for (int l = 0; l < nl; l++) {
+    LevelGeom &G = g[l];
+    memset(&G, 0, sizeof(G));
+    const float inv = h->mvInvScaleFactor[l];
+    G.w = cv_round((float)cols * inv);  // ORBextractor.cc:1192-1193
+    G.h = cv_round((float)rows * inv);
+    if (G.w < 1 || G.h < 1) { h->err = "pyramid level collapses to zero size"; return ORBX_E_ARG; }
+    G.pitch = (int)align_up((size_t)G.w, 64);
+    G.bpitch = G.pitch;
+    G.off = pyr;
+    if (l > 0) pyr += align_up((size_t)G.pitch * G.h, 256);
+    G.boff = blur;
+    blur += align_up((size_t)G.bpitch * G.h, 256);
+    // FAST grid, ORBextractor.cc:771-785
+    G.maxBorderX = G.w - ORB_EDGE_THRESHOLD + 3;
+    G.maxBorderY = G.h - ORB_EDGE_THRESHOLD + 3;
+    const float width = (float)(G.maxBorderX - ORB_MIN_BORDER), height = (float)(G.maxBorderY - ORB_MIN_BORDER);
+    const float W = 30;
+    int nCols = width > 0 ? (int)(width / W) : 0, nRows = height > 0 ? (int)(height / W) : 0;
+    if (nCols <= 0 || nRows <= 0) {  // the reference divides by zero here; defined as "no keypoints on this level"
+      nCols = nRows = 0;
+      G.wCell = G.hCell = 1;
+    } else {
+      G.wCell = (int)ceilf(width / nCols);
+      G.hCell = (int)ceilf(height / nRows);
+    }
+    G.nCols = nCols;
+    G.nRows = nRows;
+    G.cellCap = ((G.wCell + 1) / 2) * ((G.hCell + 1) / 2);
+    G.cellBase = cells;
+    G.slotBase = slots;
+    G.candBase = slots;
+    G.candCap = nCols * nRows * G.cellCap;
+    cells += nCols * nRows;
+    slots += G.candCap;
+    // octree, ORBextractor.cc:541-543
+    G.N = h->mnFeaturesPerLevel[l];
+    G.nIni = 0;
+    G.hX = 1.f;
+    if (nCols > 0) {
+      G.nIni = (int)roundf(width / height);
+      if (G.nIni < 1) { h->err = "level taller than 2x its width: the reference's DistributeOctTree has no root node"; return ORBX_E_ARG; }
+      if (G.nIni > 64) { h->err = "aspect ratio above 64 not supported"; return ORBX_E_ARG; }
+      G.hX = width / (float)G.nIni;
+    }
+    G.kpCap = std::max(G.N + 3, 4 * G.nIni) + 1;
+    G.kpBase = kps;
+    kps += G.kpCap;
+    octCap = std::max(octCap, G.kpCap + 3);
+    G.scale = h->mvScaleFactor[l];
+    G.kpsize = (float)(int)((float)ORB_PATCH_SIZE * h->mvScaleFactor[l]);  // :862
+    // blur tiles
+    G.tilesX = (G.w + 63) / 64;
+    G.tilesY = (G.h + 15) / 16;
+    G.tileBase = tiles;
+    tiles += G.tilesX * G.tilesY;
+    // resize tables, SURVEY.md A.3 (cv::resize -> hal::resize: scale = 1./(dsize/ssize))
+    G.xtabBase = (int)xtab.size();
+    G.ytabBase = (int)ytab.size();
+    if (l > 0) {
+      const int sw = g[l - 1].w, sh = g[l - 1].h;
+      const double inv_x = (double)G.w / sw, inv_y = (double)G.h / sh;
+      const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+      for (int dx = 0; dx < G.w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        int a0 = std::min(std::max(cv_round((1.f - fx) * 2048), -32768), 32767);
+        int a1 = std::min(std::max(cv_round(fx * 2048), -32768), 32767);
+        xtab.push_back(make_int2(sx, (a0 & 0xffff) | (a1 << 16)));
+      }
+      for (int dy = 0; dy < G.h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floor(fy);
+        fy -= sy;
+        int b0 = std::min(std::max(cv_round((1.f - fy) * 2048), -32768), 32767);
+        int b1 = std::min(std::max(cv_round(fy * 2048), -32768), 32767);
+        ytab.push_back(make_int2(sy, (b0 & 0xffff) | (b1 << 16)));
+      }
+    }
+  }
+  if (slots > (1 << 30)) { h->err = "workspace too large"; return ORBX_E_ARG; }
+  h->geom = g;
+  h->pyr_fs = std::max<size_t>(pyr, 256);
+  h->blur_fs = blur;
+  h->cell_fs = std::max(cells, 1);
+  h->slot_fs = (size_t)std::max(slots, 1);
+  h->cand_fs = std::max(slots, 1);
+  h->lkp_fs = kps;
+  h->totalTiles = tiles;
+  h->totalCells = cells;
+  h->totalKp = kps;
+  h->octCap = octCap;
+  h->maxKeypoints = kps;
+  const size_t B = (size_t)max_batch;
+  XCHECK(h, h->d_geom.reserve(sizeof(LevelGeom) * nl));
+  XCHECK(h, hipMemcpy(h->d_geom.p, g.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
+  XCHECK(h, h->d_pyr.reserve(h->pyr_fs * B));
+  XCHECK(h, h->d_blur.reserve(h->blur_fs * B));
+  XCHECK(h, h->d_cellCnt.reserve(sizeof(uint32_t) * h->cell_fs * B));
+  XCHECK(h, h->d_cellOff.reserve(sizeof(uint32_t) * h->cell_fs * B));
+  XCHECK(h, h->d_slots.reserve(sizeof(uint32_t) * h->slot_fs * B));
+  XCHECK(h, h->d_cand.reserve(sizeof(uint32_t) * (size_t)h->cand_fs * B));
+  XCHECK(h, h->d_knode.reserve(sizeof(uint16_t) * (size_t)h->cand_fs * B));
+  XCHECK(h, h->d_lkp.reserve(sizeof(uint32_t) * (size_t)h->lkp_fs * B));
+  XCHECK(h, h->d_lrank.reserve(sizeof(uint16_t) * (size_t)h->lkp_fs * B));
+  XCHECK(h, h->d_lcnt.reserve(sizeof(int32_t) * 2 * nl * B));
+  XCHECK(h, h->d_candCnt.reserve(sizeof(int32_t) * nl * B));
+  XCHECK(h, h->d_xtab.reserve(sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
+  XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
+  if (!xtab.empty()) XCHECK(h, hipMemcpy(h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
+  if (!ytab.empty()) XCHECK(h, hipMemcpy(h->d_ytab.p, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
+  const size_t lds = 72 * (size_t)octCap + 128;
+  if (lds > 160 * 1024 - 256) { h->err = "nfeatures too large for the LDS-resident octree"; return ORBX_E_ARG; }
+  if (lds > 48 * 1024)
+    XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  h->rows = rows;
+  h->cols = cols;
+  h->max_batch = max_batch;
+  h->have_last = false;
+  return h->maxKeypoints;
+}
+
+void orbx_set_profiling(orbx_t *h, int enable) {
+  if (!h) return;
+  h->profiling = enable != 0;
+  if (h->profiling && !h->ev_ok) {
+    (void)hipSetDevice(h->device);
+    bool ok = true;
+    for (auto &e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    h->ev_ok = ok;
+  }
+}
+
+int orbx_get_stage_ms(orbx_t *h, float *ms, int cap) {
+  if (!h || !ms || !h->profiling || !h->ev_ok || !h->stage_valid) return 0;
+  if (hipEventSynchronize(h->ev[5]) != hipSuccess) return 0;
+  int n = std::min(cap, 5);
+  for (int i = 0; i < n; i++) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]) != hipSuccess) t = -1.f;
+    ms[i] = t;
+  }
+  return n;
+}
+
+int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int cols, size_t stride, size_t frame_stride,
+                              int nframes, int lap0, int lap1, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                              int cap, void *stream_) {
+  if (!h) return ORBX_E_ARG;
+  if (!d_images || rows <= 0 || cols <= 0 || nframes <= 0) return ORBX_E_EMPTY;
+  if (!d_kps || !d_desc || !d_counts || cap <= 0 || stride < (size_t)cols) return ORBX_E_ARG;
+  int rc = orbx_configure(h, rows, cols, std::max(nframes, h->rows == rows && h->cols == cols ? h->max_batch : 1));
+  if (rc < 0) return rc;
+  XCHECK(h, hipSetDevice(h->device));
+  hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+  FrameParams P;
+  memset(&P, 0, sizeof(P));
+  P.geom = (const LevelGeom *)h->d_geom.p;
+  P.nlevels = h->nlevels;
+  P.nframes = nframes;
+  P.iniTh = h->iniThFAST;
+  P.minTh = h->minThFAST;
+  P.lap0 = lap0;
+  P.lap1 = lap1;
+  P.img0 = d_images;
+  P.img0_stride = stride;
+  P.img0_frame_stride = frame_stride;
+  P.pyr = (uint8_t *)h->d_pyr.p;       P.pyr_fs = h->pyr_fs;
+  P.blur = (uint8_t *)h->d_blur.p;     P.blur_fs = h->blur_fs;
+  P.cellCnt = (uint32_t *)h->d_cellCnt.p; P.cell_fs = h->cell_fs;
+  P.slots = (uint32_t *)h->d_slots.p;  P.slot_fs = h->slot_fs;
+  P.cand = (uint32_t *)h->d_cand.p;    P.cand_fs = h->cand_fs;
+  P.knode = (uint16_t *)h->d_knode.p;
+  P.lkp = (uint32_t *)h->d_lkp.p;      P.lkp_fs = h->lkp_fs;
+  P.lrank = (uint16_t *)h->d_lrank.p;
+  P.lcnt = (int32_t *)h->d_lcnt.p;
+  P.candCnt = (int32_t *)h->d_candCnt.p;
+  P.xtab = (const int2 *)h->d_xtab.p;
+  P.ytab = (const int2 *)h->d_ytab.p;
+  P.disc = (const int8_t *)h->d_disc.p;
+  P.totalTiles = h->totalTiles;
+  P.totalCells = h->totalCells;
+  P.totalKp = h->totalKp;
+  P.octCap = h->octCap;
+  P.out_kps = d_kps;
+  P.out_desc = d_desc;
+  P.out_counts = d_counts;
+  P.cap = cap;
+  const bool prof = h->profiling && h->ev_ok;
+  h->stage_valid = false;
+  if (prof) XCHECK(h, hipEventRecord(h->ev[0], s));
+  for (int l = 1; l < h->nlevels; l++) {
+    const LevelGeom &G = h->geom[l];
+    dim3 grid((G.w + 255) / 256, (G.h + 3) / 4, nframes), block(64, 4, 1);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, s, P, l);
+  }
+  if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
+  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells, nframes), dim3(256), 0, s, P);
+  if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
+  hipLaunchKernelGGL(k_octree<256>, dim3(h->nlevels, nframes), dim3(256), 72 * (size_t)h->octCap + 128, s, P, (uint32_t *)h->d_cellOff.p);
+  if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
+  hipLaunchKernelGGL(k_blur, dim3(h->totalTiles, nframes), dim3(256), 0, s, P);
+  if (prof) XCHECK(h, hipEventRecord(h->ev[4], s));
+  hipLaunchKernelGGL(k_describe, dim3((h->totalKp + 3) / 4, nframes), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(k_counts, dim3((nframes + 63) / 64), dim3(64), 0, s, P);
+  if (prof) { XCHECK(h, hipEventRecord(h->ev[5], s)); h->stage_valid = true; }
+  XCHECK(h, hipGetLastError());
+  h->last = P;
+  h->have_last = true;
+  return 0;
+}
+
+int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t stride, int lap0, int lap1,
+                 orbx_keypoint_t *keypoints, uint8_t *descriptors, int cap, int *n_out) {
+  if (!h) return ORBX_E_ARG;
+  if (n_out) *n_out = 0;
+  if (!image || rows <= 0 || cols <= 0) return ORBX_E_EMPTY;  // ORBextractor.cc:1075-1076
+  if (stride < (size_t)cols || !n_out) return ORBX_E_ARG;
+  int rc = orbx_configure(h, rows, cols, h->rows == rows && h->cols == cols ? h->max_batch : 1);
+  if (rc < 0) return rc;
+  const int icap = h->maxKeypoints;
+  const size_t dstride = align_up((size_t)cols, 64);
+  XCHECK(h, hipSetDevice(h->device));
+  XCHECK(h, h->d_img.reserve(dstride * rows));
+  XCHECK(h, h->d_okps.reserve(sizeof(orbx_keypoint_t) * (size_t)icap));
+  XCHECK(h, h->d_odesc.reserve(32 * (size_t)icap));
+  XCHECK(h, h->d_ocounts.reserve(sizeof(int32_t) * 2));
+  XCHECK(h, hipMemcpy2DAsync(h->d_img.p, dstride, image, stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, h->stream));
+  rc = orbx_extract_batch_device(h, (const uint8_t *)h->d_img.p, rows, cols, dstride, dstride * rows, 1, lap0, lap1,
+                                 (orbx_keypoint_t *)h->d_okps.p, (uint8_t *)h->d_odesc.p, (int32_t *)h->d_ocounts.p, icap, h->stream);
+  if (rc < 0) return rc;
+  int32_t counts[2] = {0, 0};
+  XCHECK(h, hipMemcpyAsync(counts, h->d_ocounts.p, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  *n_out = counts[0];
+  if (counts[0] > cap) return ORBX_E_CAP;
+  if (counts[0] > 0) {
+    if (!keypoints || !descriptors) return ORBX_E_ARG;
+    XCHECK(h, hipMemcpy(keypoints, h->d_okps.p, sizeof(orbx_keypoint_t) * (size_t)counts[0], hipMemcpyDeviceToHost));
+    XCHECK(h, hipMemcpy(descriptors, h->d_odesc.p, 32 * (size_t)counts[0], hipMemcpyDeviceToHost));
+  }
+  return counts[1];
+}
+
+int orbx_level_info(const orbx_t *h, int level, int *rows, int *cols) {
+  if (!h || level < 0 || level >= h->nlevels || h->geom.empty()) return ORBX_E_ARG;
+  if (rows) *rows = h->geom[level].h;
+  if (cols) *cols = h->geom[level].w;
+  return 0;
+}
+
+static int download_plane(orbx_t *h, const uint8_t *src, size_t spitch, int w, int hh, int border, uint8_t *dst, size_t dst_stride) {
+  std::vector<uint8_t> tmp((size_t)w * hh);
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  XCHECK(h, hipDeviceSynchronize());
+  XCHECK(h, hipMemcpy2D(tmp.data(), (size_t)w, src, spitch, (size_t)w, (size_t)hh, hipMemcpyDeviceToHost));
+  auto refl = [](int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+  };
+  for (int y = -border; y < hh + border; y++) {
+    const uint8_t *S = tmp.data() + (size_t)refl(y, hh) * w;
+    uint8_t *D = dst + (size_t)(y + border) * dst_stride;
+    for (int x = -border; x < w + border; x++) D[x + border] = S[refl(x, w)];
+  }
+  return 0;
+}
+
+int orbx_download_level(orbx_t *h, int frame, int level, int border, uint8_t *dst, size_t dst_stride) {
+  if (!h || !h->have_last || !dst || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes || border < 0) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  const LevelGeom &G = h->geom[level];
+  if (dst_stride < (size_t)(G.w + 2 * border)) return ORBX_E_ARG;
+  if (level == 0)
+    return download_plane(h, h->last.img0 + (size_t)frame * h->last.img0_frame_stride, h->last.img0_stride, G.w, G.h, border, dst, dst_stride);
+  return download_plane(h, h->last.pyr + (size_t)frame * h->last.pyr_fs + G.off, (size_t)G.pitch, G.w, G.h, border, dst, dst_stride);
+}
+
+int orbx_download_blurred_level(orbx_t *h, int frame, int level, uint8_t *dst, size_t dst_stride) {
+  if (!h || !h->have_last || !dst || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  const LevelGeom &G = h->geom[level];
+  if (dst_stride < (size_t)G.w) return ORBX_E_ARG;
+  return download_plane(h, h->last.blur + (size_t)frame * h->last.blur_fs + G.boff, (size_t)G.bpitch, G.w, G.h, 0, dst, dst_stride);
+}
+
+static int download_packed(orbx_t *h, const uint32_t *src, int n, float *xyr, int cap) {
+  std::vector<uint32_t> tmp((size_t)std::max(n, 1));
+  if (n > 0) XCHECK(h, hipMemcpy(tmp.data(), src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap; i++) {
+    xyr[3 * i] = (float)(tmp[i] & 0xfff);
+    xyr[3 * i + 1] = (float)((tmp[i] >> 12) & 0xfff);
+    xyr[3 * i + 2] = (float)(tmp[i] >> 24);
+  }
+  return n;
+}
+
+int orbx_download_candidates(orbx_t *h, int frame, int level, float *xyr, int cap) {
+  if (!h || !h->have_last || !xyr || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  XCHECK(h, hipDeviceSynchronize());
+  int32_t n = 0;
+  XCHECK(h, hipMemcpy(&n, h->last.candCnt + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+  return download_packed(h, h->last.cand + (size_t)frame * h->last.cand_fs + h->geom[level].candBase, n, xyr, cap);
+}
+
+int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, int cap) {
+  if (!h || !h->have_last || !xyr || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  XCHECK(h, hipDeviceSynchronize());
+  int32_t n[2] = {0, 0};
+  XCHECK(h, hipMemcpy(n, h->last.lcnt + ((size_t)frame * h->nlevels + level) * 2, sizeof(n), hipMemcpyDeviceToHost));
+  return download_packed(h, h->last.lkp + (size_t)frame * h->last.lkp_fs + h->geom[level].kpBase, n[0], xyr, cap);
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------------------------
+// matcher
+// --------------------------------------------------------------------------------------------------------------
+struct orbm_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c;
+  bool profiling = false;
+  hipEvent_t ev[2] = {};
+  bool ev_ok = false, ms_valid = false;
+  std::string err;
+};
+
+#define MCHECK(m, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return ORBX_E_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+template <int CPT>
+static void launch_search(const MatchProblemSet &M, int npairs, hipStream_t s) {
+  hipLaunchKernelGGL(k_search_by_projection<CPT>, dim3(npairs), dim3(MATCH_NT), 0, s, M);
+}
+
+extern "C" {
+
+orbm_t *orbm_create(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  orbm_handle *m = new orbm_handle();
+  m->device = device;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return nullptr; }
+  return m;
+}
+
+void orbm_destroy(orbm_t *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
+                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c};
+  for (DevBuf *b : bufs) b->release();
+  if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); }
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+const char *orbm_last_error(const orbm_t *m) { return m ? m->err.c_str() : "null handle"; }
+
+void orbm_set_profiling(orbm_t *m, int enable) {
+  if (!m) return;
+  m->profiling = enable != 0;
+  if (m->profiling && !m->ev_ok) {
+    (void)hipSetDevice(m->device);
+    m->ev_ok = hipEventCreate(&m->ev[0]) == hipSuccess && hipEventCreate(&m->ev[1]) == hipSuccess;
+  }
+}
+
+float orbm_get_last_ms(orbm_t *m) {
+  if (!m || !m->profiling || !m->ev_ok || !m->ms_valid) return -1.f;
+  float t = -1.f;
+  if (hipEventSynchronize(m->ev[1]) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&t, m->ev[0], m->ev[1]) != hipSuccess) return -1.f;
+  return t;
+}
+
+// ORBmatcher.cc:2463-2483 (the bit trick there computes exactly popcount)
+int orbm_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    dist += __builtin_popcount(pa ^ pb);
+  }
+  return dist;
+}
+
+void orbm_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3) {  // ORBmatcher.cc:2416-2458
+  int max1 = 0, max2 = 0, max3 = 0;
+  *ind1 = *ind2 = *ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = histo[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+    else if (s > max3) { max3 = s; *ind3 = i; }
+  }
+  if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+  else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+float orbm_radius_by_viewing_cos(float viewCos) { return ((double)viewCos > 0.998) ? 2.5f : 4.0f; }  // ORBmatcher.cc:216-222
+
+void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float *u, float *v) {
+  if (cam_type == 0) {  // Pinhole.cpp:46-49
+    *u = p[0] * X / Z + p[2];
+    *v = p[1] * Y / Z + p[3];
+  } else {  // KannalaBrandt8.cpp:29-45
+    const float x2_plus_y2 = X * X + Y * Y;
+    const float theta = atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = atan2f(Y, X);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+                theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    *u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);  // ::cos(double), see DESIGN.md
+    *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+  }
+}
+
+int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int frame_stride, const int32_t *d_frame_n,
+                                           int frame_n_stride, const orbm_queries_t *q, int query_stride,
+                                           const int32_t *d_query_n, int query_n_stride, int npairs, float nnratio,
+                                           int th_dist, int use_second, int32_t *d_slot, uint8_t *d_slot_obs,
+                                           int32_t *d_moq, int32_t *d_bd, int32_t *d_nm, void *stream_) {
+  if (!m || !f || !q || npairs <= 0 || !d_slot || !d_slot_obs) return ORBX_E_ARG;
+  if (!f->keys_un || !f->descriptors || !q->descriptors || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level) return ORBX_E_ARG;
+  if (!(f->max_x > f->min_x) || !(f->max_y > f->min_y)) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = stream_ ? (hipStream_t)stream_ : m->stream;
+  MatchProblemSet M;
+  memset(&M, 0, sizeof(M));
+  M.kp = reinterpret_cast<const float *>(f->keys_un);
+  M.desc = f->descriptors;
+  M.u_right = f->u_right;
+  M.frame_stride = frame_stride;
+  M.frame_n = d_frame_n; M.frame_n_stride = frame_n_stride; M.frame_n_const = f->n;
+  M.min_x = f->min_x; M.min_y = f->min_y;
+  M.inv_w = (float)ORBM_GRID_COLS / (f->max_x - f->min_x);   // Frame.cc:379
+  M.inv_h = (float)ORBM_GRID_ROWS / (f->max_y - f->min_y);   // Frame.cc:380
+  M.qdesc = q->descriptors; M.qu = q->u; M.qv = q->v; M.qr = q->radius; M.qur = q->u_r;
+  M.qminl = q->min_level; M.qmaxl = q->max_level; M.qflags = q->flags;
+  M.query_stride = query_stride;
+  M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
+  M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
+  M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
+  const int maxn = d_frame_n ? frame_stride : f->n;
+  if (maxn > 32 * MATCH_NT) { m->err = "more than 8192 keypoints per frame not supported by the search kernel"; return ORBX_E_ARG; }
+  const bool prof = m->profiling && m->ev_ok;
+  m->ms_valid = false;
+  if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
+  if (maxn <= 5 * MATCH_NT) launch_search<5>(M, npairs, s);
+  else if (maxn <= 8 * MATCH_NT) launch_search<8>(M, npairs, s);
+  else if (maxn <= 16 * MATCH_NT) launch_search<16>(M, npairs, s);
+  else launch_search<32>(M, npairs, s);
+  if (prof) { MCHECK(m, hipEventRecord(m->ev[1], s)); m->ms_valid = true; }
+  MCHECK(m, hipGetLastError());
+  return 0;
+}
+
+int orbm_search_by_projection(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist,
+                              int use_second, int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist) {
+  if (!m || !f || !q || !slot || !slot_obs) return ORBX_E_ARG;
+  const int n = f->n, nq = q->nq;
+  if (n < 0 || nq < 0) return ORBX_E_ARG;
+  if (n == 0 || nq == 0) {
+    for (int i = 0; i < nq; i++) { if (match_of_query) match_of_query[i] = -1; if (best_dist) best_dist[i] = 256; }
+    return 0;
+  }
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+#define UP(buf, src, bytes)                                                               \
+  do {                                                                                    \
+    MCHECK(m, (buf).reserve(bytes));                                                      \
+    MCHECK(m, hipMemcpyAsync((buf).p, (src), (bytes), hipMemcpyHostToDevice, s));         \
+  } while (0)
+  UP(m->d_kp, f->keys_un, sizeof(orbx_keypoint_t) * (size_t)n);
+  UP(m->d_desc, f->descriptors, 32 * (size_t)n);
+  if (f->u_right) UP(m->d_ur, f->u_right, sizeof(float) * (size_t)n);
+  UP(m->d_qdesc, q->descriptors, 32 * (size_t)nq);
+  UP(m->d_qf[0], q->u, sizeof(float) * (size_t)nq);
+  UP(m->d_qf[1], q->v, sizeof(float) * (size_t)nq);
+  UP(m->d_qf[2], q->radius, sizeof(float) * (size_t)nq);
+  if (q->u_r) UP(m->d_qf[3], q->u_r, sizeof(float) * (size_t)nq);
+  UP(m->d_qi[0], q->min_level, sizeof(int32_t) * (size_t)nq);
+  UP(m->d_qi[1], q->max_level, sizeof(int32_t) * (size_t)nq);
+  if (q->flags) UP(m->d_qfl, q->flags, (size_t)nq);
+  UP(m->d_slot, slot, sizeof(int32_t) * (size_t)n);
+  UP(m->d_sobs, slot_obs, (size_t)n);
+#undef UP
+  MCHECK(m, m->d_moq.reserve(sizeof(int32_t) * (size_t)nq));
+  MCHECK(m, m->d_bd.reserve(sizeof(int32_t) * (size_t)nq));
+  MCHECK(m, m->d_nm.reserve(sizeof(int32_t)));
+  orbm_frame_t df = *f;
+  df.keys_un = (const orbx_keypoint_t *)m->d_kp.p;
+  df.descriptors = (const uint8_t *)m->d_desc.p;
+  df.u_right = f->u_right ? (const float *)m->d_ur.p : nullptr;
+  orbm_queries_t dq = *q;
+  dq.descriptors = (const uint8_t *)m->d_qdesc.p;
+  dq.u = (const float *)m->d_qf[0].p;
+  dq.v = (const float *)m->d_qf[1].p;
+  dq.radius = (const float *)m->d_qf[2].p;
+  dq.u_r = q->u_r ? (const float *)m->d_qf[3].p : nullptr;
+  dq.min_level = (const int32_t *)m->d_qi[0].p;
+  dq.max_level = (const int32_t *)m->d_qi[1].p;
+  dq.flags = q->flags ? (const uint8_t *)m->d_qfl.p : nullptr;
+  int rc = orbm_search_by_projection_batch_device(m, &df, n, nullptr, 0, &dq, nq, nullptr, 0, 1, nnratio, th_dist, use_second,
+                                                  (int32_t *)m->d_slot.p, (uint8_t *)m->d_sobs.p, (int32_t *)m->d_moq.p,
+                                                  (int32_t *)m->d_bd.p, (int32_t *)m->d_nm.p, s);
+  if (rc < 0) return rc;
+  int32_t nm = 0;
+  MCHECK(m, hipMemcpyAsync(slot, m->d_slot.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipMemcpyAsync(slot_obs, m->d_sobs.p, (size_t)n, hipMemcpyDeviceToHost, s));
+  if (match_of_query) MCHECK(m, hipMemcpyAsync(match_of_query, m->d_moq.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
+  if (best_dist) MCHECK(m, hipMemcpyAsync(best_dist, m->d_bd.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipMemcpyAsync(&nm, m->d_nm.p, sizeof(nm), hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  return nm;
+}
+
+int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
+  if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  MCHECK(m, m->d_a.reserve(32 * (size_t)nq));
+  MCHECK(m, m->d_b.reserve(32 * (size_t)nc));
+  MCHECK(m, m->d_c.reserve(sizeof(uint16_t) * (size_t)nq * nc));
+  MCHECK(m, hipMemcpyAsync(m->d_a.p, q, 32 * (size_t)nq, hipMemcpyHostToDevice, s));
+  MCHECK(m, hipMemcpyAsync(m->d_b.p, c, 32 * (size_t)nc, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_hamming_matrix, dim3((nq + 255) / 256), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc,
+                     (uint16_t *)m->d_c.p);
+  MCHECK(m, hipGetLastError());
+  MCHECK(m, hipMemcpyAsync(dist, m->d_c.p, sizeof(uint16_t) * (size_t)nq * nc, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""GPU parity tests of the extractor: HIP path (through the C ABI) vs the CPU oracle on the same seeded frames.
+Bit-exact: every comparison is array_equal on bytes / float32 bit patterns."""
+import numpy as np
+import pytest
+
+from conftest import EUROC, TUMVI
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ex(pkg):
+    e = pkg.ORBextractor(**EUROC)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oex(oracle):
+    return oracle.OracleExtractor(**EUROC)
+
+
+def assert_kps_equal(k1, k2):
+    assert len(k1) == len(k2)
+    for f in k1.dtype.names:
+        a, b = k1[f], k2[f]
+        assert np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), f
+
+
+@pytest.mark.parametrize("seed", [1000, 1001])
+def test_stage_parity(ex, oex, oracle, frame, seed):
+    img = frame(seed)
+    mono, kps, desc = ex(img, None, (0, 1000))
+    pyr = oex.pyramid(img)
+    q = oex.features_per_level
+    for l in range(8):
+        assert ex.level_shape(l) == pyr[l].shape
+        assert np.array_equal(ex.image_pyramid_level(l), pyr[l]), "pyramid level %d" % l
+        assert np.array_equal(ex.blurred_level(l), oracle.gaussian_blur7(pyr[l])), "blur level %d" % l
+        c_ref = oex.level_candidates(pyr[l])
+        c_gpu = ex.level_candidates(l)
+        assert np.array_equal(c_gpu, c_ref), "FAST candidates level %d" % l
+        h, w = pyr[l].shape
+        k_ref = oracle.distribute_octtree(c_ref, 16, w - 16, 16, h - 16, q[l])
+        k_gpu = ex.level_keypoints(l)
+        assert np.array_equal(k_gpu, k_ref), "octree level %d" % l
+
+
+def test_pyramid_border(ex, oex, oracle, frame):
+    """mvImagePyramid with its 19-px BORDER_REFLECT_101 frame (ORBextractor.cc:1203-1215)."""
+    img = frame(1000)
+    ex(img)
+    pyr = oex.pyramid(img)
+    for l in (0, 3, 7):
+        h, w = pyr[l].shape
+        ref = np.zeros((h + 38, w + 38), dtype=np.uint8)
+        import ctypes as C
+        oracle.lib().orc_copy_make_border101(pyr[l].ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), ref.ctypes.data_as(C.c_void_p), 19, C.c_size_t(w + 38))
+        assert np.array_equal(ex.image_pyramid_level(l, border=19), ref)
+
+
+@pytest.mark.parametrize("seed", [1000, 1001, 1002, 1003, 1004])
+@pytest.mark.parametrize("lap", [(0, 1000), (0, 0)])
+def test_extract_parity_euroc(ex, oex, frame, seed, lap):
+    img = frame(seed)
+    mono, kps, desc = ex(img, None, lap)
+    mono_r, kps_r, desc_r = oex.extract(img, lap)
+    assert mono == mono_r
+    assert_kps_equal(kps, kps_r)
+    assert np.array_equal(desc, desc_r)
+    assert len(kps) >= 1000
+
+
+@pytest.mark.parametrize("seed", [2000, 2001])
+def test_extract_parity_tumvi(pkg, oracle, frame, seed):
+    img = frame(seed, 512, 512)
+    e = pkg.ORBextractor(**TUMVI)
+    o = oracle.OracleExtractor(**TUMVI)
+    mono, kps, desc = e(img, None, (0, 1000))
+    mono_r, kps_r, desc_r = o.extract(img, (0, 1000))
+    assert mono == mono_r
+    assert_kps_equal(kps, kps_r)
+    assert np.array_equal(desc, desc_r)
+    e.close()
+
+
+def test_ini_extractor_5000(pkg, oracle, frame):
+    """mpIniORBextractor = 5*nFeatures (Tracking.cc:844): exercises the large-N octree (LDS > 64 KB)."""
+    img = frame(1000)
+    e = pkg.ORBextractor(5000, 1.2, 8, 20, 7)
+    o = oracle.OracleExtractor(5000, 1.2, 8, 20, 7)
+    mono, kps, desc = e(img, None, (0, 1000))
+    mono_r, kps_r, desc_r = o.extract(img, (0, 1000))
+    assert mono == mono_r
+    assert_kps_equal(kps, kps_r)
+    assert np.array_equal(desc, desc_r)
+    e.close()
+
+
+def test_lapping_partial(ex, oex, frame):
+    img = frame(1002)
+    for lap in [(300, 500), (0, 375), (376, 2000)]:
+        mono, kps, desc = ex(img, None, lap)
+        mono_r, kps_r, desc_r = oex.extract(img, lap)
+        assert mono == mono_r and 0 < mono < len(kps)
+        assert_kps_equal(kps, kps_r)
+        assert np.array_equal(desc, desc_r)
+
+
+def test_edge_cases(pkg, oracle, ex, oex):
+    # empty image -> -1 (ORBextractor.cc:1075-1076)
+    mono, kps, desc = ex(np.zeros((0, 0), dtype=np.uint8))
+    assert mono == -1 and len(kps) == 0
+    # constant image: no corners, zero keypoints, descriptors released (:1100-1101)
+    flat = np.full((480, 752), 77, dtype=np.uint8)
+    mono, kps, desc = ex(flat)
+    mono_r, kps_r, _ = oex.extract(flat)
+    assert mono == mono_r == 0 and len(kps) == len(kps_r) == 0
+    # non-contiguous rows (cv::Mat step > cols)
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (480, 800), dtype=np.uint8)
+    view = big[:, 10:10 + 752]
+    mono, kps, desc = ex(view)
+    mono_r, kps_r, desc_r = oex.extract(np.ascontiguousarray(view))
+    assert mono == mono_r
+    assert_kps_equal(kps, kps_r)
+    assert np.array_equal(desc, desc_r)
+    # pure noise (maximum candidate density) and odd sizes
+    for (H, W) in [(480, 752), (241, 377), (100, 131)]:
+        img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        e = pkg.ORBextractor(**EUROC)
+        mono, kps, desc = e(img)
+        mono_r, kps_r, desc_r = oex.extract(img)
+        assert mono == mono_r
+        assert_kps_equal(kps, kps_r)
+        assert np.array_equal(desc, desc_r)
+        e.close()
+    # wrong type
+    with pytest.raises(ValueError):
+        ex(np.zeros((480, 752), dtype=np.float32))
+
+
+def test_batch_device_api(pkg, oex, frame):
+    """orbx_extract_batch_device: 6 frames resident in HBM, outputs in HBM, compared frame by frame."""
+    import torch
+    seeds = [1000, 1001, 1002, 1003, 1004, 1005]
+    imgs = np.stack([frame(s) for s in seeds])
+    B, H, W = imgs.shape
+    e = pkg.ORBextractor(**EUROC)
+    cap = e.configure(H, W, B)
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for lap in [(0, 1000), (0, 0)]:
+        e.extract_batch_device(d_img.data_ptr(), H, W, W, H * W, B, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap, lap, stream=s)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        kps_all = d_kps.cpu().numpy()
+        desc_all = d_desc.cpu().numpy()
+        for b, seed in enumerate(seeds):
+            mono_r, kps_r, desc_r = oex.extract(imgs[b], lap)
+            n = int(cnt[b, 0])
+            assert n == len(kps_r) and int(cnt[b, 1]) == mono_r
+            kps = kps_all[b, :n].copy().view(pkg.KP_DTYPE).reshape(-1)
+            assert_kps_equal(kps, kps_r)
+            assert np.array_equal(desc_all[b, :n], desc_r)
+    e.close()
+
+
+def test_full_size_properties(pkg, frame):
+    """Size-independent properties at BASELINE's full batch size: determinism (same frames twice -> same bytes),
+    frame independence (a frame's result does not depend on its batch neighbours), quota respected."""
+    import torch
+    B = 64
+    base = np.stack([frame(1000 + (i % 8)) for i in range(B)])
+    e = pkg.ORBextractor(**EUROC)
+    cap = e.configure(480, 752, B)
+    d_img = torch.from_numpy(base).cuda()
+    outs = []
+    for rep in range(2):
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        e.extract_batch_device(d_img.data_ptr(), 480, 752, 752, 480 * 752, B, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), cap,
+                               (0, 1000), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append((d_kps.cpu().numpy(), d_desc.cpu().numpy(), d_cnt.cpu().numpy()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    kps, desc, cnt = outs[0]
+    for i in range(8, B):
+        n = cnt[i, 0]
+        assert n == cnt[i % 8, 0] and np.array_equal(kps[i, :n], kps[i % 8, :n]) and np.array_equal(desc[i, :n], desc[i % 8, :n])
+    assert (cnt[:, 0] >= 1000).all() and (cnt[:, 0] <= cap).all()
+    e.close()

@@ -1,0 +1,135 @@
+"""GPU parity tests of the ORBmatcher path: projection search with sequential claim semantics, best/second ratio
+test, grid-walk tie order -- HIP (through the C ABI) vs the CPU oracle.  Index-exact."""
+import numpy as np
+import pytest
+
+from conftest import EUROC
+
+pytestmark = pytest.mark.gpu
+
+
+def make_frame_pair(pkg, oracle, synth, seed, shift=(5, -3)):
+    """Two synthetic frames related by an integer shift, extracted with the oracle (inputs for the matcher)."""
+    frames, offs = synth.make_stream(seed, 2)
+    o = oracle.OracleExtractor(**EUROC)
+    _, k0, d0 = o.extract(frames[0])
+    _, k1, d1 = o.extract(frames[1])
+    return (k0, d0), (k1, d1), offs, o.scale_factors
+
+
+def both_frames(pkg, oracle, k1, d1, sf, bounds=(0.0, 752.0, 0.0, 480.0)):
+    F = pkg.FrameView(k1, d1, bounds)
+    OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
+    return F, OF
+
+
+@pytest.fixture(scope="module")
+def matcher(pkg):
+    m = pkg.ORBmatcher(0.8, True)
+    yield m
+    m.close()
+
+
+def test_hamming_matrix(pkg, matcher, synth):
+    q, c = synth.make_descriptor_sets(2000, n=1000)
+    d = matcher.hamming_matrix(q, c)
+    ref = np.unpackbits(q[:, None, :] ^ c[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(d, ref.astype(np.uint16))
+    d2 = matcher.hamming_matrix(q[:7], c[:301])
+    assert np.array_equal(d2, ref[:7, :301].astype(np.uint16))
+
+
+@pytest.mark.parametrize("seed", [3000, 3001])
+def test_search_by_projection_m2(pkg, oracle, synth, matcher, seed):
+    """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th): map points = keypoints of frame t-1."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, seed)
+    F, OF = both_frames(pkg, oracle, k1, d1, sf)
+    nq = len(k0)
+    rng = np.random.default_rng(seed)
+    projX = (k0["x"] + np.float32(offs[0][0] - offs[1][0])).astype(np.float32)
+    projY = (k0["y"] + np.float32(offs[0][1] - offs[1][1])).astype(np.float32)
+    viewCos = rng.choice(np.array([0.9, 0.9985, 1.0], dtype=np.float32), nq)
+    level = k0["octave"].astype(np.int32)
+    in_view = (rng.random(nq) < 0.9).astype(np.uint8)
+    obs = (rng.random(nq) < 0.85).astype(np.uint8)
+    for th in (1.0, 3.0):
+        F.slot[:] = -1; F.slot_obs[:] = 0; OF.slot[:] = -1; OF.slot_obs[:] = 0
+        n_gpu, moq_gpu, _ = matcher.SearchByProjection(F, in_view, d0, projX, projY, viewCos, level, sf, th=th, mp_obs=obs)
+        n_ref, moq_ref = OF.search_by_projection_mp(in_view, d0, projX, projY, viewCos, level, th, 0.8, qobs=obs)
+        assert n_gpu == n_ref and n_ref > 200
+        assert np.array_equal(moq_gpu, moq_ref)
+        assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+
+
+def test_search_stress_1000x1000(pkg, oracle, synth, matcher):
+    """BASELINE config 3 stress: window = whole image, levels open -> every query sees every keypoint; sequential
+    claims on; nnratio 0.8; TH_HIGH 100."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3100)
+    F, OF = both_frames(pkg, oracle, k1, d1, sf)
+    nq = len(k0)
+    u = (k0["x"] + np.float32(offs[0][0] - offs[1][0])).astype(np.float32)
+    v = (k0["y"] + np.float32(offs[0][1] - offs[1][1])).astype(np.float32)
+    radius = np.full(nq, 1.0e4, np.float32)
+    ml = np.full(nq, -1, np.int32)
+    n_gpu, moq_gpu, bd_gpu = matcher.search_window(F, d0, u, v, radius, ml, ml, nnratio=0.8, th_dist=100, use_second=True)
+    n_ref, moq_ref, bd_ref = OF.search_by_projection_win(d0, u, v, radius, ml, ml, 0.8, 100, True)
+    assert n_gpu == n_ref and n_ref > 300
+    assert np.array_equal(moq_gpu, moq_ref) and np.array_equal(bd_gpu, bd_ref)
+    assert np.array_equal(F.slot, OF.slot)
+
+
+def test_claims_and_ties(pkg, oracle, matcher):
+    """Collisions: duplicated descriptors (distance ties decided by grid-walk order), duplicated queries (later
+    queries lose a claimed keypoint only if the holder has observations), pre-occupied slots."""
+    rng = np.random.default_rng(11)
+    N = 600
+    kps = np.zeros(N, dtype=pkg.KP_DTYPE)
+    kps["x"] = rng.uniform(5, 747, N).astype(np.float32)
+    kps["y"] = rng.uniform(5, 475, N).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, N)
+    kps["angle"] = rng.uniform(0, 360, N).astype(np.float32)
+    base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    desc = base[rng.integers(0, 40, N)].copy()            # heavy duplication -> ties everywhere
+    flip = rng.random((N, 32)) < 0.02
+    desc[flip] ^= 1
+    sf = np.array([1.2 ** i for i in range(8)], dtype=np.float32)
+    F, OF = both_frames(pkg, oracle, kps, desc, sf)
+    occ = rng.random(N) < 0.2
+    F.slot[occ] = 9999; OF.slot[occ] = 9999
+    F.slot_obs[occ] = (rng.random(occ.sum()) < 0.5); OF.slot_obs[:] = F.slot_obs
+    nq = 500
+    qi = rng.integers(0, N, nq)
+    qdesc = desc[qi].copy()
+    u = (kps["x"][qi] + rng.uniform(-3, 3, nq)).astype(np.float32)
+    v = (kps["y"][qi] + rng.uniform(-3, 3, nq)).astype(np.float32)
+    radius = rng.choice(np.array([10.0, 40.0, 200.0], dtype=np.float32), nq)
+    minl = rng.integers(-1, 4, nq).astype(np.int32)
+    maxl = np.where(rng.random(nq) < 0.3, -1, minl + rng.integers(0, 5, nq)).astype(np.int32)
+    obs = (rng.random(nq) < 0.6).astype(np.uint8)
+    inv = (rng.random(nq) < 0.95).astype(np.uint8)
+    flags = inv | (obs << 1)
+    for use_second in (True, False):
+        F.slot[:] = np.where(occ, 9999, -1); OF.slot[:] = F.slot
+        F.slot_obs[:] = OF.slot_obs
+        so0 = OF.slot_obs.copy()
+        n_gpu, moq_gpu, bd_gpu = matcher.search_window(F, qdesc, u, v, radius, minl, maxl, flags=flags, nnratio=0.7, th_dist=60, use_second=use_second)
+        n_ref, moq_ref, bd_ref = OF.search_by_projection_win(qdesc, u, v, radius, minl, maxl, 0.7, 60, use_second, qobs=obs, in_view=inv)
+        assert n_gpu == n_ref and n_ref > 50
+        assert np.array_equal(moq_gpu, moq_ref) and np.array_equal(bd_gpu, bd_ref)
+        assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+        OF.slot_obs[:] = so0; F.slot_obs[:] = so0
+
+
+def test_empty_and_ragged(pkg, oracle, matcher):
+    kps = np.zeros(3, dtype=pkg.KP_DTYPE)
+    kps["x"] = [10, 700, -50]       # one keypoint outside the grid (PosInGrid false, Frame.cc:821-822)
+    kps["y"] = [10, 400, 100]
+    desc = np.zeros((3, 32), np.uint8)
+    F = pkg.FrameView(kps, desc, (0.0, 752.0, 0.0, 480.0))
+    n, moq, bd = matcher.search_window(F, np.zeros((0, 32), np.uint8), [], [], [], [], [])
+    assert n == 0 and len(moq) == 0
+    n, moq, bd = matcher.search_window(F, np.zeros((2, 32), np.uint8), [12.0, -48.0], [11.0, 100.0], [5.0, 5.0], [-1, -1], [-1, -1], th_dist=100, use_second=False)
+    assert n == 1 and moq.tolist() == [0, -1]
+    F0 = pkg.FrameView(kps[:0], desc[:0], (0.0, 752.0, 0.0, 480.0))
+    n, moq, bd = matcher.search_window(F0, np.zeros((2, 32), np.uint8), [12.0, 5.0], [11.0, 5.0], [5.0, 5.0], [-1, -1], [-1, -1])
+    assert n == 0 and moq.tolist() == [-1, -1]
