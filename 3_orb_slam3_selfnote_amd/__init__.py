@@ -57,6 +57,14 @@ def load(build_if_needed=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Two HIP
+    # runtimes in one process cannot both own the device, so when torch is installed it is imported FIRST: the
+    # loader then resolves liborbhip.so's NEEDED libamdhip64.so.7 to the copy torch already mapped, and torch
+    # tensors, streams and liborbhip kernels share one runtime.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc"):
         _build.build()
     if not os.path.exists(LIB_PATH):
