@@ -220,7 +220,8 @@ class ORBextractor:
 
     def extract_batch_device(self, d_images, rows, cols, stride, frame_stride, nframes, d_kps, d_desc, d_counts, cap,
                              vLappingArea=(0, 1000), stream=None):
-        """All pointers are device addresses (ints).  Asynchronous on `stream` (hipStream_t as int; None = own)."""
+        """All pointers are device addresses (ints).  Asynchronous on `stream` (hipStream_t as int; None/0 = the
+        device's default stream, which is also torch's default current stream)."""
         rc = self.L.orbx_extract_batch_device(self.h, C.c_void_p(d_images), int(rows), int(cols), C.c_size_t(stride),
                                               C.c_size_t(frame_stride), int(nframes), int(vLappingArea[0]),
                                               int(vLappingArea[1]), C.c_void_p(d_kps), C.c_void_p(d_desc),

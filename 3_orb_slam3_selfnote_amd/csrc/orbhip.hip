@@ -369,7 +369,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   int rc = orbx_configure(h, rows, cols, std::max(nframes, h->rows == rows && h->cols == cols ? h->max_batch : 1));
   if (rc < 0) return rc;
   XCHECK(h, hipSetDevice(h->device));
-  hipStream_t s = stream_ ? (hipStream_t)stream_ : h->stream;
+  hipStream_t s = (hipStream_t)stream_;  // verbatim: NULL is the device's default stream
   FrameParams P;
   memset(&P, 0, sizeof(P));
   P.geom = (const LevelGeom *)h->d_geom.p;
@@ -655,7 +655,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (!f->keys_un || !f->descriptors || !q->descriptors || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level) return ORBX_E_ARG;
   if (!(f->max_x > f->min_x) || !(f->max_y > f->min_y)) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));
-  hipStream_t s = stream_ ? (hipStream_t)stream_ : m->stream;
+  hipStream_t s = (hipStream_t)stream_;  // verbatim: NULL is the device's default stream
   MatchProblemSet M;
   memset(&M, 0, sizeof(M));
   M.kp = reinterpret_cast<const float *>(f->keys_un);

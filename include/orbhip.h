@@ -8,7 +8,7 @@
  *
  * Plain pointers and sizes only.  "host" entry points take host memory and synchronise before returning;
  * "_device" entry points take device memory, are asynchronous on `stream` (a hipStream_t passed as void*,
- * NULL = the handle's own stream) and never touch the host.
+ * used verbatim: NULL = the device's default stream) and never touch the host.
  *
  * Return convention: >= 0 success (function specific), < 0 error:
  *   ORBX_E_EMPTY (-1)  empty image            (ORBextractor.cc:1075-1076 returns -1)
