@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms",
 ]
 
@@ -106,6 +106,8 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, f32, i32, i32,
                                                          vp, vp, vp, vp, vp, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.orbm_search_by_projection_last_frame.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32,
+                                                       i32, i32, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_radius_by_viewing_cos.restype = f32
     L.orbm_radius_by_viewing_cos.argtypes = [f32]
@@ -377,6 +379,25 @@ class ORBmatcher:
         flags = (np.asarray(mp_in_view, dtype=np.uint8) & 1) | ((obs & 1) << 1)
         return self.search_window(F, mp_desc, mp_projX, mp_projY, radius, lvl - 1, lvl, flags=flags, u_r=mp_projXR,
                                   nnratio=self.mfNNratio, th_dist=self.TH_HIGH, use_second=True)
+
+    def SearchByProjectionLastFrame(self, CurrentFrame, scale_factors, has_mp, Xw, mp_desc, last_keys, Tcw, Tlw, cam_type,
+                                    cam_params, th, bMono=True, mb=0.0, mbf=0.0, mp_obs=None):
+        """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) -- ORBmatcher.cc:2027-2289."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf = a(scale_factors, np.float32)
+        has_mp, Xw, mp_desc = a(has_mp, np.uint8), a(Xw, np.float32), a(mp_desc, np.uint8)
+        last_keys = a(last_keys, KP_DTYPE)
+        Tcw, Tlw, cam_params = a(Tcw, np.float32), a(Tlw, np.float32), a(cam_params, np.float32)
+        obs = None if mp_obs is None else a(mp_obs, np.uint8)
+        fs = CurrentFrame.struct()
+        rc = self.L.orbm_search_by_projection_last_frame(self.m, C.byref(fs), _p(sf), len(sf), len(has_mp), _p(has_mp), _p(Xw),
+                                                         _p(mp_desc), _p(last_keys), _p(obs), _p(Tcw), _p(Tlw), int(cam_type),
+                                                         _p(cam_params), C.c_float(mb), C.c_float(mbf), C.c_float(th), int(bool(bMono)),
+                                                         int(self.mbCheckOrientation), _p(CurrentFrame.slot), _p(CurrentFrame.slot_obs))
+        self._check(rc, "orbm_search_by_projection_last_frame")
+        if rc < 0:
+            raise OrbError("orbm_search_by_projection_last_frame rc=%d" % rc)
+        return rc
 
     def hamming_matrix(self, q, c):
         q = np.ascontiguousarray(q, dtype=np.uint8)

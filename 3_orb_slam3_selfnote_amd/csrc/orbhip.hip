@@ -746,6 +746,83 @@ int orbm_search_by_projection(orbm_t *m, const orbm_frame_t *f, const orbm_queri
   return nm;
 }
 
+// cv::Mat products of ORBmatcher.cc:2038-2047, :2072 restated: a 3x3 * 3x1 `A*B + C` MatExpr is a single
+// cv::gemm whose small-matrix float path forms a0*b0 + a1*b1 + a2*b2 in float, then adds C; `-A.t()*B` takes the
+// generic path that accumulates in double.  [OPENCV-UNVERIFIED], identical in the test oracle.
+static void mat3_mul_add(const float *R, const float *x, const float *t, float *out) {  // R: row-major, row stride 4
+  for (int i = 0; i < 3; i++) {
+    float t0 = R[i * 4 + 0] * x[0] + R[i * 4 + 1] * x[1] + R[i * 4 + 2] * x[2];
+    out[i] = (float)((double)t0 + (double)t[i]);
+  }
+}
+
+int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, const float *sf, int nlevels, int nLast,
+                                         const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
+                                         const orbx_keypoint_t *last_keys, const uint8_t *obs, const float *Tcw,
+                                         const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
+                                         float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs) {
+  if (!m || !cur || !sf || nLast < 0 || !Tcw || !Tlw || !cam_params || !slot || !slot_obs) return ORBX_E_ARG;
+  if (nLast > 0 && (!has_mp || !Xw || !mpdesc || !last_keys)) return ORBX_E_ARG;
+  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]}, tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+  float twc[3], tlc[3];
+  for (int i = 0; i < 3; i++) {  // twc = -Rcw.t()*tcw, :2041
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)tcw[k];
+    twc[i] = (float)(s * -1.0);
+  }
+  mat3_mul_add(Tlw, twc, tlw, tlc);  // tlc = Rlw*twc+tlw, :2047
+  const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;  // :2051-2052
+  std::vector<float> u(nLast), v(nLast), rad(nLast), ur(nLast);
+  std::vector<int32_t> minl(nLast), maxl(nLast), moq(nLast);
+  std::vector<uint8_t> flags(nLast);
+  for (int i = 0; i < nLast; i++) {
+    flags[i] = 0; u[i] = v[i] = rad[i] = ur[i] = 0.f; minl[i] = maxl[i] = -1;
+    if (!has_mp[i]) continue;
+    float x3Dc[3];
+    mat3_mul_add(Tcw, Xw + 3 * i, tcw, x3Dc);                  // :2072
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);        // :2076
+    if (invzc < 0) continue;
+    float ux, vy;
+    orbm_project(cam_type, cam_params, x3Dc[0], x3Dc[1], x3Dc[2], &ux, &vy);  // :2091
+    if (ux < cur->min_x || ux > cur->max_x) continue;          // :2094-2097
+    if (vy < cur->min_y || vy > cur->max_y) continue;
+    const int nLastOctave = last_keys[i].octave;
+    if (nLastOctave < 0 || nLastOctave >= nlevels) return ORBX_E_ARG;
+    u[i] = ux; v[i] = vy;
+    rad[i] = th * sf[nLastOctave];                             // :2105
+    if (bForward) { minl[i] = nLastOctave; maxl[i] = -1; }     // :2113-2118
+    else if (bBackward) { minl[i] = 0; maxl[i] = nLastOctave; }
+    else { minl[i] = nLastOctave - 1; maxl[i] = nLastOctave + 1; }
+    ur[i] = ux - mbf * invzc;                                  // :2141
+    flags[i] = (uint8_t)(1u | ((obs ? (obs[i] & 1u) : 1u) << 1));
+  }
+  orbm_queries_t q;
+  q.nq = nLast; q.descriptors = mpdesc; q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = ur.data(); q.flags = flags.data();
+  int nmatches = orbm_search_by_projection(m, cur, &q, 0.f, ORBM_TH_HIGH, 0, slot, slot_obs, moq.data(), nullptr);
+  if (nmatches < 0 || !checkOri) return nmatches;
+  // rotation consistency, :2177-2185 and :2263-2286 (factor = 1/HISTO_LENGTH, so only bins 0..12 are reachable)
+  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+  const float factor = 1.0f / ORBM_HISTO_LENGTH;
+  for (int i = 0; i < nLast; i++) {
+    if (moq[i] < 0) continue;
+    float rot = last_keys[i].angle - cur->keys_un[moq[i]].angle;
+    if ((double)rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+    if (bin < 0 || bin >= ORBM_HISTO_LENGTH) continue;
+    rotHist[bin].push_back(moq[i]);
+  }
+  int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+  orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (int idx : rotHist[i]) { slot[idx] = -1; slot_obs[idx] = 0; nmatches--; }
+  }
+  return nmatches;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

@@ -170,6 +170,22 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *frame0
                                            uint8_t *d_slot_obs, int32_t *d_match_of_query, int32_t *d_best_dist,
                                            int32_t *d_nmatches, void *stream);
 
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+ * (ORBmatcher.cc:2027-2289, Nleft == -1 path), flattened.  Host pointers.
+ * Last-frame side, i in [0, nLast): has_mp[i] = LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i];
+ * Xw[3i..] = pMP->GetWorldPos(); mpdesc[32i..] = pMP->GetDescriptor(); last_keys[i] = LastFrame.mvKeys[i]
+ * (octave) / mvKeysUn[i] (angle); obs[i] = pMP->Observations()>0 (NULL = all 1).
+ * Tcw / Tlw = CurrentFrame.mTcw / LastFrame.mTcw, row-major 4x4.  cam_type/cam_params: CurrentFrame.mpCamera
+ * (see orbm_project).  mb, mbf: CurrentFrame.mb / mbf.  scale_factors = CurrentFrame.mvScaleFactors.
+ * The projection (:2072-2097), window selection (:2105-2118) and the rotation-histogram pruning (:2177-2185,
+ * :2263-2286) run on the host in fp32 exactly as written in the reference; the Hamming search with its sequential
+ * claims runs on the device.  slot / slot_obs as in orbm_search_by_projection.  Returns nmatches. */
+int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, const float *scale_factors, int nlevels,
+                                         int nLast, const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
+                                         const orbx_keypoint_t *last_keys, const uint8_t *obs, const float *Tcw,
+                                         const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
+                                         float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

@@ -133,3 +133,50 @@ def test_empty_and_ragged(pkg, oracle, matcher):
     F0 = pkg.FrameView(kps[:0], desc[:0], (0.0, 752.0, 0.0, 480.0))
     n, moq, bd = matcher.search_window(F0, np.zeros((2, 32), np.uint8), [12.0, 5.0], [11.0, 5.0], [5.0, 5.0], [-1, -1], [-1, -1])
     assert n == 0 and moq.tolist() == [-1, -1]
+
+
+def _m3_scene(pkg, oracle, synth, seed, cam, stereo):
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, seed)
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375            # Examples/Monocular/EuRoC.yaml:9-12
+    n0 = len(k0)
+    z = np.float32(5.0)
+    Xw = np.stack([(k0["x"] - np.float32(cx)) / np.float32(fx) * z, (k0["y"] - np.float32(cy)) / np.float32(fy) * z,
+                   np.full(n0, z, np.float32)], axis=1).astype(np.float32)
+    Xw[rng.random(n0) < 0.03, 2] = -1.0                               # behind the camera -> invzc < 0
+    dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+    ang = 0.002
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    Tcw[:3, 3] = [dx * z / fx, dy * z / fy, -0.3 if stereo else 0.0]
+    Tlw = np.eye(4, dtype=np.float32)
+    has_mp = (rng.random(n0) < 0.8).astype(np.uint8)
+    obs = (rng.random(n0) < 0.9).astype(np.uint8)
+    if cam == 0:
+        params = np.array([fx, fy, cx, cy], np.float32)
+    else:                                                             # Examples/Monocular/TUM_512.yaml:9-19, centred on this image
+        params = np.array([190.978477 * 2, 190.973307 * 2, 376.0, 240.0, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736], np.float32)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(k1)) < 0.7, k1["x"] - np.float32(47.9) / z, np.float32(-1)).astype(np.float32)
+    return k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, u_right
+
+
+@pytest.mark.parametrize("cam,stereo", [(0, False), (0, True), (1, False)])
+def test_search_by_projection_last_frame_m3(pkg, oracle, synth, matcher, cam, stereo):
+    """ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) incl. camera projection (Pinhole /
+    KannalaBrandt8), forward/backward level windows, stereo right-coordinate check and rotation-histogram pruning."""
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, u_right = _m3_scene(pkg, oracle, synth, 3200 + cam, cam, stereo)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    total = 0
+    for th in (15.0, 30.0):
+        F = pkg.FrameView(k1, d1, bounds, u_right=u_right)
+        OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf, u_right=u_right)
+        mb, mbf = (0.11, 47.9) if stereo else (0.0, 0.0)
+        n_gpu = matcher.SearchByProjectionLastFrame(F, sf, has_mp, Xw, d0, k0, Tcw, Tlw, cam, params, th, bMono=not stereo, mb=mb, mbf=mbf, mp_obs=obs)
+        n_ref = OF.search_by_projection_ff(has_mp, Xw, d0, k0["octave"], k0["angle"], Tcw, Tlw, cam, params, th, mono=not stereo,
+                                           check_ori=True, mb=mb, mbf=mbf, qobs=obs)
+        assert n_gpu == n_ref
+        assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+        total += n_ref
+    assert total > (100 if cam == 0 else 0)
