@@ -163,11 +163,26 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
   return min(max(S, 0), 255);
 }
 
+// Necessary condition for "corner at threshold t" on the 4 compass pixels (k = 0, 4, 8, 12): every arc of 9 contiguous
+// circle pixels contains two ADJACENT compass pixels, so two adjacent ones must both be darker than v-t or both
+// brighter than v+t.  Pixels that fail it at minThFAST have S <= minThFAST and can never be emitted nor suppress a
+// neighbour, so their score is left at 0 and the 16-pixel score is only evaluated for the survivors.
+__device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
+  constexpr int Pt = FAST_TILE_PITCH;
+  const int v = c[0];
+  const int p0 = c[3 * Pt], p4 = c[3], p8 = c[-3 * Pt], p12 = c[-3];
+  const int lo = v - t, hi = v + t;
+  const uint32_t d = (p0 < lo ? 1u : 0u) | (p4 < lo ? 2u : 0u) | (p8 < lo ? 4u : 0u) | (p12 < lo ? 8u : 0u);
+  const uint32_t b = (p0 > hi ? 1u : 0u) | (p4 > hi ? 2u : 0u) | (p8 > hi ? 4u : 0u) | (p12 > hi ? 8u : 0u);
+  const uint32_t dr = d | (d << 4), br = b | (b << 4);  // rotate: adjacency incl. 12 -> 0
+  return ((dr & (dr >> 1)) | (br & (br >> 1))) & 0xfu;
+}
+
 __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
-  __shared__ uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
+  __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
-  __shared__ uint8_t sM[60 * 60];
-  __shared__ uint32_t sCount;
+  __shared__ uint16_t sList[60 * 60];
+  __shared__ uint32_t sCount, sNList;
   __shared__ uint32_t sWave[16 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int cellId = blockIdx.x, frame = blockIdx.y;
@@ -188,29 +203,66 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   }
   int pitch;
   const uint8_t *img = level_plane(P, frame, level, pitch);
-  // tile -> LDS
-  for (int idx = tid; idx < tw * th; idx += 256) {
-    int r = idx / tw, cc = idx - r * tw;
-    sT[r * FAST_TILE_PITCH + cc] = img[(size_t)(iniY + r) * pitch + iniX + cc];
+  // ---- tile -> LDS.  Aligned path: dword loads of the columns [iniX & ~3, ...), tile column 0 = image column ax.
+  const int ax = iniX & ~3, ox = iniX - ax;           // ox: offset of the cell's first column inside the tile
+  const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
+  if (aligned) {
+    const int ndw = (ox + tw + 3) >> 2;               // dwords per tile row (<= 18)
+    const uint32_t magic = 0xffffffffu / (uint32_t)ndw + 1u;
+    for (int idx = tid; idx < ndw * th; idx += 256) {
+      const int r = (int)__umulhi((uint32_t)idx, magic), d = idx - r * ndw;
+      // the last dword of a row may reach past the image row; it stays inside the plane's pitch padding / next row
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(img + (size_t)(iniY + r) * pitch + ax + 4 * d);
+      *reinterpret_cast<uint32_t *>(&sT[r * FAST_TILE_PITCH + 4 * d]) = v;
+    }
+  } else {
+    const uint32_t magic = 0xffffffffu / (uint32_t)tw + 1u;
+    for (int idx = tid; idx < tw * th; idx += 256) {
+      const int r = (int)__umulhi((uint32_t)idx, magic), cc = idx - r * tw;
+      sT[r * FAST_TILE_PITCH + ox + cc] = img[(size_t)(iniY + r) * pitch + iniX + cc];
+    }
   }
-  for (int idx = tid; idx < (ch + 2) * FAST_S_PITCH; idx += 256) sS[idx] = 0;
-  if (tid == 0) sCount = 0;
+  for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += 256) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
+  if (tid == 0) { sCount = 0; sNList = 0; }
   __syncthreads();
   const int npx = cw * ch;
-  for (int p = tid; p < npx; p += 256) {
-    int y = p / cw, x = p - y * cw;
-    int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + x + 3]);
+  const int tmin = min(P.iniTh, P.minTh);
+  const uint32_t magicw = 0xffffffffu / (uint32_t)cw + 1u;  // p / cw for p < 2^16 (exact: p*cw < 2^32)
+  // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list
+  for (int p0 = 0; p0 < npx; p0 += 256) {
+    const int p = p0 + tid;
+    bool pass = false;
+    if (p < npx) {
+      const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
+      pass = fast_compass_test(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3], tmin);
+    }
+    const unsigned long long b = __ballot(pass);
+    uint32_t wbase = 0;
+    if (lane == 0 && b) wbase = atomicAdd(&sNList, (uint32_t)__popcll(b));
+    wbase = __shfl(wbase, 0, WAVE);
+    if (pass) sList[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
+  }
+  __syncthreads();
+  // ---- pass 2: full 16-pixel score for the survivors only
+  const int nlist = (int)sNList;
+  for (int e = tid; e < nlist; e += 256) {
+    const int p = sList[e];
+    const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
+    const int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3]);
     sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
   }
   __syncthreads();
-  // 3x3 strict maximum inside the cell; votes for the iniThFAST set
+  // ---- pass 3: 3x3 strict maximum inside the cell (threshold independent); vote for the iniThFAST set
+  uint8_t *sM = reinterpret_cast<uint8_t *>(sList);  // the work list is dead: reuse it as the kept-score plane
   uint32_t myIni = 0;
   for (int p = tid; p < npx; p += 256) {
-    int y = p / cw, x = p - y * cw;
+    const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
     const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
-    int S = s[0];
-    bool keep = S >= 2 && S > s[-1] && S > s[1] && S > s[-FAST_S_PITCH - 1] && S > s[-FAST_S_PITCH] &&
-                S > s[-FAST_S_PITCH + 1] && S > s[FAST_S_PITCH - 1] && S > s[FAST_S_PITCH] && S > s[FAST_S_PITCH + 1];
+    const int S = s[0];
+    bool keep = false;
+    if (S > tmin && S >= 2)
+      keep = S > s[-1] && S > s[1] && S > s[-FAST_S_PITCH - 1] && S > s[-FAST_S_PITCH] && S > s[-FAST_S_PITCH + 1] &&
+             S > s[FAST_S_PITCH - 1] && S > s[FAST_S_PITCH] && S > s[FAST_S_PITCH + 1];
     sM[p] = keep ? (uint8_t)S : 0;
     myIni += (keep && S > P.iniTh) ? 1u : 0u;
   }
@@ -218,7 +270,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   if (lane == 0 && anyv) atomicOr(&sCount, 1u);
   __syncthreads();
   const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, ORBextractor.cc:825-828
-  // raster-order compaction: pixel p = k*256 + tid; wave w of iteration k owns pixels [k*256+64w, +64)
+  // ---- pass 4: raster-order compaction: pixel p = k*256 + tid; wave w of iteration k owns pixels [k*256+64w, +64)
   const int niter = (npx + 255) / 256;
   for (int k = 0; k < niter; k++) {
     int p = k * 256 + tid;
@@ -237,7 +289,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     for (int w = 0; w < wid; w++) woff += sWave[k * 4 + w];
     if (f) {
       uint32_t rank = base + woff + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-      int y = p / cw, x = p - y * cw;
+      const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
       uint32_t X = (uint32_t)(cj * G.wCell + x + 3), Y = (uint32_t)(ci * G.hCell + y + 3);
       if (rank < (uint32_t)G.cellCap) slots[rank] = ((uint32_t)(sM[p] - 1) << 24) | (Y << 12) | X;
     }
@@ -549,9 +601,12 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
 // K5: cv::GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101, 8U fixed point: taps {18,34,49,55,49,34,18},
 // row sums exact in 16 bits, (sum + 32768) >> 16 after the column pass.  64x16 output tile per workgroup.
 // ------------------------------------------------------------------------------------------------------------
+#define BLUR_TX 128
+#define BLUR_TY 32
 __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
-  __shared__ uint8_t sIn[22 * 72];
-  __shared__ uint16_t sRow[22 * 64];
+  // input tile: rows y0-3 .. y0+34 (38), columns x0-4 .. x0+131 (136 B = 34 dwords); row sums: 38 x 128 u16
+  __shared__ uint32_t sIn[38 * 34];
+  __shared__ uint32_t sRow[38 * 64];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, frame = blockIdx.y;
   int level = 0;
@@ -560,31 +615,68 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   const LevelGeom G = P.geom[level];
   const int t = tile - G.tileBase;
   const int ty = t / G.tilesX, tx = t - ty * G.tilesX;
-  const int x0 = tx * 64, y0 = ty * 16;
+  const int x0 = tx * BLUR_TX, y0 = ty * BLUR_TY;
   int pitch;
   const uint8_t *img = level_plane(P, frame, level, pitch);
-  for (int idx = tid; idx < 22 * 70; idx += 256) {
-    int r = idx / 70, c = idx - r * 70;
-    int yy = reflect101(y0 + r - 3, G.h), xx = reflect101(x0 + c - 3, G.w);
-    sIn[r * 72 + c] = img[(size_t)yy * pitch + xx];
+  const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
+  for (int idx = tid; idx < 38 * 34; idx += 256) {
+    const int r = idx / 34, c = idx - r * 34;
+    const int yy = reflect101(y0 + r - 3, G.h);
+    const int xb = x0 - 4 + 4 * c;
+    const uint8_t *row = img + (size_t)yy * pitch;
+    uint32_t v;
+    if (aligned && xb >= 0 && xb + 3 < G.w) {
+      v = *reinterpret_cast<const uint32_t *>(row + xb);
+    } else {
+      v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
+          ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
+    }
+    sIn[idx] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < 22 * 64; idx += 256) {
-    int r = idx >> 6, c = idx & 63;
-    const uint8_t *s = &sIn[r * 72 + c];
-    uint32_t v = 18u * (s[0] + s[6]) + 34u * (s[1] + s[5]) + 49u * (s[2] + s[4]) + 55u * s[3];
-    sRow[idx] = (uint16_t)v;
+  // horizontal pass: thread = 4 consecutive outputs of one row; taps as two byte-quads for v_dot4_u32_u8
+  const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+  for (int idx = tid; idx < 38 * 32; idx += 256) {
+    const int r = idx >> 5, q = idx & 31;
+    const uint32_t d0 = sIn[r * 34 + q], d1 = sIn[r * 34 + q + 1], d2 = sIn[r * 34 + q + 2];
+    // output k (x = x0+4q+k) uses bytes [1+k, 7+k] of the 12-byte window d0|d1|d2
+    uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false);
+    s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, s0, false);
+    uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false);
+    s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, s1, false);
+    uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false);
+    s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, s2, false);
+    uint32_t s3 = __builtin_amdgcn_udot4(d1, K0, 0u, false);
+    s3 = __builtin_amdgcn_udot4(d2, K1, s3, false);
+    sRow[r * 64 + 2 * q] = s0 | (s1 << 16);        // row sums <= 257*255 = 65535: exact in 16 bits
+    sRow[r * 64 + 2 * q + 1] = s2 | (s3 << 16);
   }
   __syncthreads();
-  uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff;
-  for (int idx = tid; idx < 16 * 64; idx += 256) {
-    int r = idx >> 6, c = idx & 63;
-    const uint16_t *s = &sRow[r * 64 + c];
-    uint32_t v = 18u * ((uint32_t)s[0] + s[6 * 64]) + 34u * ((uint32_t)s[64] + s[5 * 64]) +
-                 49u * ((uint32_t)s[2 * 64] + s[4 * 64]) + 55u * (uint32_t)s[3 * 64];
-    v = (v + 32768u) >> 16;
-    v = v > 255u ? 255u : v;
-    if (x0 + c < G.w && y0 + r < G.h) out[(size_t)(y0 + r) * G.bpitch + x0 + c] = (uint8_t)v;
+  // vertical pass: thread = 4 columns x 4 rows, 10-row window read once
+  {
+    const int q = tid & 31, rg = tid >> 5;  // column quad 0..31, row group 0..7
+    uint32_t a[10], b[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) { a[j] = sRow[(rg * 4 + j) * 64 + 2 * q]; b[j] = sRow[(rg * 4 + j) * 64 + 2 * q + 1]; }
+    uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      uint32_t px[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {
+#define RS(j) ((cc < 2 ? a[rr + (j)] : b[rr + (j)]) >> ((cc & 1) * 16) & 0xffffu)
+        uint32_t v = 18u * (RS(0) + RS(6)) + 34u * (RS(1) + RS(5)) + 49u * (RS(2) + RS(4)) + 55u * RS(3);
+#undef RS
+        v = (v + 32768u) >> 16;
+        px[cc] = v > 255u ? 255u : v;
+      }
+      const int y = y0 + rg * 4 + rr, x = x0 + 4 * q;
+      if (y < G.h) {
+        uint8_t *o = out + (size_t)y * G.bpitch + x;
+        if (x + 3 < G.w) *reinterpret_cast<uint32_t *>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        else for (int cc = 0; cc < 4 && x + cc < G.w; cc++) o[cc] = (uint8_t)px[cc];
+      }
+    }
   }
 }
 

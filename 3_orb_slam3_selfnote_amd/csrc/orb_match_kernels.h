@@ -43,17 +43,213 @@ __device__ __forceinline__ void merge2(unsigned long long &b, unsigned long long
   b = nb;
 }
 
-// One workgroup per (frame, query set).  Each thread keeps CPT candidate keypoints (descriptor, position, octave,
-// grid cell) in registers; queries are resolved strictly in order -- the reference's loops carry a dependency
-// through F.mvpMapPoints (ORBmatcher.cc:89-91/:130, :2135-2137/:2162) -- with one workgroup-wide
-// (best, second) reduction per query.
+// ---------------------------------------------------------------------------------------------------------------
+// Projection search = two kernels.
+//
+// The reference resolves queries strictly in order because a keypoint claimed by an earlier map point is skipped by
+// later ones (ORBmatcher.cc:89-91/:130, :2135-2137/:2162).  Claims only ever REMOVE candidates, so:
+//   k_match_scan     (fully parallel, all the Hamming work): for every query the TOPK smallest reduction keys over all
+//                    candidates that pass the static tests (grid-cell window, level window, |dx|,|dy| < r, stereo
+//                    check, not held by an occupant with observations).
+//   k_match_resolve  (one workgroup per frame pair, in query order): the first two entries of a query's list that are
+//                    still unclaimed ARE its best / second-best at its turn; the query is rescanned (exact, all waves
+//                    of the workgroup split the keypoints) only if fewer than two survive AND an unlisted candidate
+//                    could still change the decision.  Then the reference's accept rule (:124-130 resp. :2159-2162)
+//                    and the claim.
 //
 // Candidate enumeration order of Frame::GetFeaturesInArea (Frame.cc:781-809: ix outer, iy inner, insertion order)
-// decides argmin ties (strict <, first minimum wins): it is carried in the reduction key
-//   key = dist<<40 | (ix*48+iy)<<28 | idx<<8 | octave.
-template <int CPT>
-__global__ __launch_bounds__(MATCH_NT) void k_search_by_projection(MatchProblemSet M) {
-  __shared__ unsigned long long sRed[2][2 * (MATCH_NT / 64)];
+// decides argmin ties (strict <, first minimum wins); it is carried in the key below the distance:
+//   Key32 (frames of <= 2048 keypoints): dist<<23 | (ix*48+iy)<<11 | idx     -- one v_min_u32 per comparison
+//   Key64 (up to 32768 keypoints):       dist<<40 | (ix*48+iy)<<28 | idx<<8
+// ---------------------------------------------------------------------------------------------------------------
+#define MATCH_TOPK 8
+#define MATCH_CH 128
+#define RESOLVE_NW 8
+
+struct Key32 {
+  typedef uint32_t T;
+  static constexpr T NONE = 0xffffffffu;
+  static __device__ __forceinline__ T make(int dist, uint32_t cell, int idx) { return ((uint32_t)dist << 23) | (cell << 11) | (uint32_t)idx; }
+  static __device__ __forceinline__ int dist(T k) { return (int)(k >> 23); }
+  static __device__ __forceinline__ int idx(T k) { return (int)(k & 0x7ffu); }
+  static __device__ __forceinline__ T shfl_xor(T v, int o) { return __shfl_xor(v, o, 64); }
+  static __device__ __forceinline__ T readlane(T v, int l) { return (T)__builtin_amdgcn_readlane((int)v, l); }
+};
+struct Key64 {
+  typedef unsigned long long T;
+  static constexpr T NONE = ~0ull;
+  static __device__ __forceinline__ T make(int dist, uint32_t cell, int idx) { return ((T)dist << 40) | ((T)cell << 28) | ((T)idx << 8); }
+  static __device__ __forceinline__ int dist(T k) { return (int)(k >> 40); }
+  static __device__ __forceinline__ int idx(T k) { return (int)((k >> 8) & 0xfffff); }
+  static __device__ __forceinline__ T shfl_xor(T v, int o) { return shfl_xor_u64(v, o); }
+  static __device__ __forceinline__ T readlane(T v, int l) {
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((T)hi << 32) | lo;
+  }
+};
+
+struct CandMeta { float x, y; uint32_t bits; float ur; };  // bits: octave | gx<<8 | gy<<16 | usable<<24
+
+__device__ __forceinline__ uint32_t cand_bits(float x, float y, int oct, bool claimed, const MatchProblemSet &M) {
+  // Frame::PosInGrid, Frame.cc:815-825
+  int gx = (int)roundf((x - M.min_x) * M.inv_w), gy = (int)roundf((y - M.min_y) * M.inv_h);
+  bool in = gx >= 0 && gx < 64 && gy >= 0 && gy < 48;
+  return (uint32_t)(oct & 0xff) | ((uint32_t)(gx & 0xff) << 8) | ((uint32_t)(gy & 0xff) << 16) | ((in && !claimed) ? (1u << 24) : 0u);
+}
+__device__ __forceinline__ uint32_t cell_of(uint32_t bits) { return ((bits >> 8) & 0xff) * 48u + ((bits >> 16) & 0xff); }
+
+struct QueryWin { float u, v, r, ur; int minl, maxl, cx0, cx1, cy0, cy1; bool live, checkLevels, stereo; };
+
+__device__ __forceinline__ QueryWin load_query(const MatchProblemSet &M, size_t qo, int q) {
+  QueryWin w;
+  const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
+  w.u = M.qu[qo + q]; w.v = M.qv[qo + q]; w.r = M.qr[qo + q];
+  w.minl = M.qminl[qo + q]; w.maxl = M.qmaxl[qo + q];
+  w.ur = M.qur ? M.qur[qo + q] : 0.f;
+  // Frame::GetFeaturesInArea cell window, Frame.cc:755-777
+  w.cx0 = max(0, (int)floorf((w.u - M.min_x - w.r) * M.inv_w));
+  w.cx1 = min(63, (int)ceilf((w.u - M.min_x + w.r) * M.inv_w));
+  w.cy0 = max(0, (int)floorf((w.v - M.min_y - w.r) * M.inv_h));
+  w.cy1 = min(47, (int)ceilf((w.v - M.min_y + w.r) * M.inv_h));
+  w.live = (fl & 1) && w.cx0 < 64 && w.cx1 >= 0 && w.cy0 < 48 && w.cy1 >= 0;
+  w.checkLevels = (w.minl > 0) || (w.maxl >= 0);
+  w.stereo = M.u_right != nullptr;
+  return w;
+}
+
+__device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y, uint32_t bits, float cur) {
+  const int oct = bits & 0xff, gx = (bits >> 8) & 0xff, gy = (bits >> 16) & 0xff;
+  bool ok = (bits >> 24) & 1u;
+  ok = ok && gx >= w.cx0 && gx <= w.cx1 && gy >= w.cy0 && gy <= w.cy1;
+  if (w.checkLevels) ok = ok && oct >= w.minl && (w.maxl < 0 || oct <= w.maxl);
+  ok = ok && fabsf(x - w.u) < w.r && fabsf(y - w.v) < w.r;
+  if (w.stereo && cur > 0.f) ok = ok && !(fabsf(w.ur - cur) > w.r);  // ORBmatcher.cc:93-98, :2139-2146
+  return ok;
+}
+
+template <typename KT>
+__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk) {
+  typedef typename KT::T K;
+  __shared__ uint4 sDesc[MATCH_CH * 2];
+  __shared__ CandMeta sMeta[MATCH_CH];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  if ((int)(blockIdx.x * MATCH_NT) >= nq) return;
+  const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
+  const float *kp = M.kp + fo * 7;
+  const uint4 *desc = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
+  const int q = blockIdx.x * MATCH_NT + tid;
+  QueryWin w;
+  w.live = false;
+  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (q < nq) {
+    w = load_query(M, qo, q);
+    const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
+    uint4 a = qp[0], b = qp[1];
+    qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+  }
+  K top[MATCH_TOPK];
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
+  for (int base = 0; base < n; base += MATCH_CH) {
+    const int m = min(MATCH_CH, n - base);
+    __syncthreads();
+    if (tid < 2 * m) sDesc[tid] = desc[(size_t)base * 2 + tid];
+    if (tid < m) {
+      const int i = base + tid;
+      CandMeta c;
+      c.x = kp[(size_t)i * 7];
+      c.y = kp[(size_t)i * 7 + 1];
+      const int oct = __float_as_int(kp[(size_t)i * 7 + 5]);
+      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
+      const bool claimed = M.slot[fo + i] >= 0 && M.slot_obs[fo + i];
+      c.bits = cand_bits(c.x, c.y, oct, claimed, M);
+      sMeta[tid] = c;
+    }
+    __syncthreads();
+    if (w.live) {
+      for (int c = 0; c < m; c++) {
+        const CandMeta cm = sMeta[c];
+        if (cand_passes(w, cm.x, cm.y, cm.bits, cm.ur)) {
+          const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+          const int dist = __popc(a.x ^ qd[0]) + __popc(a.y ^ qd[1]) + __popc(a.z ^ qd[2]) + __popc(a.w ^ qd[3]) +
+                           __popc(b.x ^ qd[4]) + __popc(b.y ^ qd[5]) + __popc(b.z ^ qd[6]) + __popc(b.w ^ qd[7]);
+          K t = KT::make(dist, cell_of(cm.bits), base + c);
+          if (t < top[MATCH_TOPK - 1]) {
+#pragma unroll
+            for (int j = 0; j < MATCH_TOPK; j++) {
+              const K lo = t < top[j] ? t : top[j];
+              const K hi = t < top[j] ? top[j] : t;
+              top[j] = lo;
+              t = hi;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (q < nq) {
+    K *o = topk + (qo + q) * MATCH_TOPK;
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];
+  }
+}
+
+// Accept rule shared by both paths (ORBmatcher.cc:124-130 resp. :2159-2162).
+__device__ __forceinline__ bool accept_rule(const MatchProblemSet &M, bool has1, int bd, int lvl1, bool has2, int d2, int lvl2) {
+  if (!has1 || bd > M.th_dist) return false;
+  if (M.use_second && has2 && lvl1 == lvl2 && (float)bd > M.nnratio * (float)d2) return false;
+  return true;
+}
+
+// Per-lane decision from a query's sorted candidate list, the "entry is claimed" mask and the entries' octaves
+// (4 bits each).  Returns accept<<31 | rescan<<30 | bestIdx; *bd_out = distance of the best surviving entry.
+//
+// Every candidate that is not in the list has key >= tk[TOPK-1], i.e. distance >= lbDist.  A rescan is needed only
+// when an unlisted candidate could change the decision:
+//   no survivor          and an unlisted one could be within th_dist;
+//   one survivor (best)  and the unknown second-best could make the ratio test fail (ORBmatcher.cc:126).
+template <typename KT>
+__device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typename KT::T (&tk)[MATCH_TOPK], uint32_t cm, uint32_t oct4, int *bd_out) {
+  typedef typename KT::T K;
+  K best = KT::NONE, second = KT::NONE;
+  int found = 0, l1 = 0, l2 = 0;
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) {
+    const bool av = tk[j] != KT::NONE && !((cm >> j) & 1u);
+    const int lv = (int)((oct4 >> (4 * j)) & 0xfu);
+    const bool s2 = av && found == 1, s1 = av && found == 0;
+    second = s2 ? tk[j] : second; l2 = s2 ? lv : l2;
+    best = s1 ? tk[j] : best; l1 = s1 ? lv : l1;
+    found += av ? 1 : 0;
+  }
+  const bool truncated = tk[MATCH_TOPK - 1] != KT::NONE;
+  const int lbDist = KT::dist(tk[MATCH_TOPK - 1]);
+  const int bd = found > 0 ? KT::dist(best) : 256;
+  bool rescan = false;
+  if (truncated) {
+    if (found == 0) rescan = lbDist <= M.th_dist;
+    else if (found == 1 && M.use_second) rescan = bd <= M.th_dist && (float)bd > M.nnratio * (float)lbDist;
+  }
+  const bool acc = !rescan && accept_rule(M, found > 0, bd, l1, found > 1, KT::dist(second), l2);
+  *bd_out = bd;
+  return (acc ? 0x80000000u : 0u) | (rescan ? 0x40000000u : 0u) | (found > 0 ? (uint32_t)KT::idx(best) : 0u);
+}
+
+// One workgroup (RESOLVE_NW wavefronts) per problem, queries in order.  EVERY wave replays the same sequential turn
+// loop on its own private copy of the claim bitmap (bits only ever go 0 -> 1, the loop is deterministic, so the
+// copies never diverge and no per-turn barrier is needed); the waves only meet in a rescan, where they split the
+// keypoints and exchange their partial (best, second) through LDS.  Wave 0 also records the new slot holders.
+// Each lane owns one query of the current 64-query chunk and keeps its decision current: a turn = one readlane of
+// lane i's decision, the claim, and a re-decide in the lanes whose lists contain the claimed keypoint.
+// LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that rescans never leave the CU.
+template <typename KT, bool LDSCAND>
+__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn) {
+  typedef typename KT::T K;
+  extern __shared__ __align__(16) uint32_t smem_resolve[];
+  __shared__ K sPart[2][RESOLVE_NW][2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -63,99 +259,151 @@ __global__ __launch_bounds__(MATCH_NT) void k_search_by_projection(MatchProblemS
   const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
   int32_t *slot = M.slot + fo;
   uint8_t *slot_obs = M.slot_obs + fo;
-
-  uint32_t cd[CPT][8];
-  float cx[CPT], cy[CPT], cur[CPT];
-  int coct[CPT], ccell[CPT];
-  uint32_t claimed = 0;
-#pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    const int i = j * MATCH_NT + tid;
-    ccell[j] = -1;
-    cx[j] = cy[j] = 0.f; cur[j] = -1.f; coct[j] = 0;
-#pragma unroll
-    for (int w = 0; w < 8; w++) cd[j][w] = 0;
-    if (i < n) {
-      cx[j] = kp[(size_t)i * 7];
-      cy[j] = kp[(size_t)i * 7 + 1];
-      coct[j] = __float_as_int(kp[(size_t)i * 7 + 5]);
-      if (M.u_right) cur[j] = M.u_right[fo + i];
-#pragma unroll
-      for (int w = 0; w < 8; w++) cd[j][w] = desc[(size_t)i * 8 + w];
-      // Frame::PosInGrid, Frame.cc:815-825
-      int gx = (int)roundf((cx[j] - M.min_x) * M.inv_w), gy = (int)roundf((cy[j] - M.min_y) * M.inv_h);
-      if (gx >= 0 && gx < 64 && gy >= 0 && gy < 48) ccell[j] = gx * 48 + gy;
-      if (slot[i] >= 0 && slot_obs[i]) claimed |= 1u << j;
+  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [RESOLVE_NW claim bitmaps][slot]
+  const int cwords = ((maxn + 63) >> 6) * 2 + 2;
+  uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
+  CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
+  uint32_t *rest = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
+  volatile uint32_t *sClaim = rest + (size_t)wid * cwords;  // this wave's private copy
+  volatile int32_t *sSlot = reinterpret_cast<volatile int32_t *>(rest + (size_t)RESOLVE_NW * cwords);
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    const int i = b0 + lane;
+    const bool cl = i < n && slot[i] >= 0 && slot_obs[i];
+    const unsigned long long mask = __ballot(cl);
+    if (lane == 0) { sClaim[(b0 >> 5)] = (uint32_t)mask; sClaim[(b0 >> 5) + 1] = (uint32_t)(mask >> 32); }
+  }
+  for (int i = tid; i < n; i += 64 * RESOLVE_NW) sSlot[i] = -1;
+  if (LDSCAND) {
+    const uint4 *gd = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
+    for (int i = tid; i < 2 * n; i += 64 * RESOLVE_NW) sDesc[i] = gd[i];
+    for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+      CandMeta c;
+      c.x = kp[(size_t)i * 7];
+      c.y = kp[(size_t)i * 7 + 1];
+      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
+      c.bits = cand_bits(c.x, c.y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
+      sMeta[i] = c;
     }
   }
-  int nmatches = 0;
-  for (int q = 0; q < nq; q++) {
-    const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
-    unsigned long long best = ~0ull, second = ~0ull;
-    const float u = M.qu[qo + q], v = M.qv[qo + q], r = M.qr[qo + q];
-    const int minl = M.qminl[qo + q], maxl = M.qmaxl[qo + q];
-    // Frame::GetFeaturesInArea cell window, Frame.cc:755-777
-    int cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w));
-    int cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
-    int cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h));
-    int cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
-    const bool live = (fl & 1) && cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0;
-    const bool checkLevels = (minl > 0) || (maxl >= 0);
-    if (live) {
-      const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + q) * 32);
-      uint32_t q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3], q4 = qd[4], q5 = qd[5], q6 = qd[6], q7 = qd[7];
-      const float ur = M.qur ? M.qur[qo + q] : 0.f;
+  __syncthreads();
+  auto octave_of = [&](int idx) -> int {
+    if (LDSCAND) return (int)(sMeta[idx].bits & 0xff);
+    return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
+  };
+  int nmatches = 0, nrescan = 0;
+  for (int base = 0; base < nq; base += 64) {
+    const int q = base + lane;
+    K tk[MATCH_TOPK];
+    uint32_t cm = 0, oct4 = 0;  // bit j: entry j of my list is claimed; 4 bits per entry: its octave
 #pragma unroll
-      for (int j = 0; j < CPT; j++) {
-        const int cell = ccell[j];
-        if (cell < 0) continue;
-        const int gx = cell / 48, gy = cell - gx * 48;
-        bool ok = gx >= cx0 && gx <= cx1 && gy >= cy0 && gy <= cy1;
-        if (checkLevels) ok = ok && coct[j] >= minl && (maxl < 0 || coct[j] <= maxl);
-        ok = ok && fabsf(cx[j] - u) < r && fabsf(cy[j] - v) < r;
-        ok = ok && !((claimed >> j) & 1u);
-        if (M.u_right && cur[j] > 0.f) ok = ok && !(fabsf(ur - cur[j]) > r);  // ORBmatcher.cc:93-98, :2139-2146
-        if (ok) {
-          int dist = __popc(cd[j][0] ^ q0) + __popc(cd[j][1] ^ q1) + __popc(cd[j][2] ^ q2) + __popc(cd[j][3] ^ q3) +
-                     __popc(cd[j][4] ^ q4) + __popc(cd[j][5] ^ q5) + __popc(cd[j][6] ^ q6) + __popc(cd[j][7] ^ q7);
-          unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)cell << 28) |
-                                   ((unsigned long long)(j * MATCH_NT + tid) << 8) | (unsigned long long)(coct[j] & 0xff);
-          if (key < best) { second = best; best = key; }
-          else if (key < second) second = key;
+    for (int j = 0; j < MATCH_TOPK; j++) {
+      tk[j] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+      if (tk[j] != KT::NONE) {
+        const int idx = KT::idx(tk[j]);
+        cm |= ((sClaim[idx >> 5] >> (idx & 31)) & 1u) << j;
+        oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
+      }
+    }
+    const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
+    int my_bd;
+    uint32_t D = decide<KT>(M, tk, cm, oct4, &my_bd);
+    int res_idx = -1, res_bd = 256;
+    const int cnt = min(64, nq - base);
+    for (int i = 0; i < cnt; i++) {
+      const uint32_t Di = (uint32_t)__builtin_amdgcn_readlane((int)D, i);
+      const uint32_t ob = ((uint32_t)__builtin_amdgcn_readlane((int)myfl, i) >> 1) & 1u;
+      bool accept = (Di >> 31) & 1u;
+      int bestIdx = (int)(Di & 0xfffff);
+      if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
+      if ((Di >> 30) & 1u) {
+        // exact rescan of this query over all keypoints with the current claims; the waves split the keypoints
+        const int qq = base + i;
+        const QueryWin w = load_query(M, qo, qq);
+        const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + qq) * 32);
+        K b1 = KT::NONE, b2 = KT::NONE;
+        if (w.live) {
+          uint32_t q8[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) q8[t] = qd[t];
+          for (int c = tid; c < n; c += 64 * RESOLVE_NW) {
+            const bool cl = (sClaim[c >> 5] >> (c & 31)) & 1u;
+            float x, y, cur;
+            uint32_t bits, d8[8];
+            if (LDSCAND) {
+              const CandMeta cmeta = sMeta[c];
+              x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
+              bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
+              const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+              d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
+            } else {
+              x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
+              bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
+              cur = M.u_right ? M.u_right[fo + c] : -1.f;
+#pragma unroll
+              for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
+            }
+            if (cand_passes(w, x, y, bits, cur)) {
+              int dist = 0;
+#pragma unroll
+              for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
+              const K key = KT::make(dist, cell_of(bits), c);
+              if (key < b1) { b2 = b1; b1 = key; }
+              else if (key < b2) b2 = key;
+            }
+          }
+        }
+        // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
+        K m1 = b1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m1, o); m1 = t < m1 ? t : m1; }
+        K m2 = (b1 == m1) ? b2 : b1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m2, o); m2 = t < m2 ? t : m2; }
+        const int par = nrescan & 1;
+        nrescan++;
+        if (lane == 0) { sPart[par][wid][0] = m1; sPart[par][wid][1] = m2; }
+        __syncthreads();
+        K g1 = KT::NONE, g2 = KT::NONE;
+#pragma unroll
+        for (int ww = 0; ww < RESOLVE_NW; ww++) {
+          const K a1 = sPart[par][ww][0], a2 = sPart[par][ww][1];
+          // merge (g1<=g2) with (a1<=a2)
+          const K nb = g1 < a1 ? g1 : a1;
+          const K mx = g1 < a1 ? a1 : g1;
+          const K ms = g2 < a2 ? g2 : a2;
+          g2 = mx < ms ? mx : ms;
+          g1 = nb;
+        }
+        const bool has1 = g1 != KT::NONE, has2 = g2 != KT::NONE;
+        const int bd = has1 ? KT::dist(g1) : 256;
+        bestIdx = has1 ? KT::idx(g1) : 0;
+        accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
+        if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; }
+      }
+      if (accept) {
+        nmatches++;
+        if (lane == 0) {
+          if (ob) sClaim[bestIdx >> 5] = sClaim[bestIdx >> 5] | (1u << (bestIdx & 31));
+          if (wid == 0) sSlot[bestIdx] = (int32_t)((uint32_t)(base + i) | (ob << 30));
+        }
+        if (ob) {  // lanes whose list contains the claimed keypoint re-decide
+          uint32_t ncm = cm;
+#pragma unroll
+          for (int j = 0; j < MATCH_TOPK; j++)
+            if (tk[j] != KT::NONE && KT::idx(tk[j]) == bestIdx) ncm |= 1u << j;
+          if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      unsigned long long ob = shfl_xor_u64(best, o), os = shfl_xor_u64(second, o);
-      merge2(best, second, ob, os);
+    if (wid == 0 && q < nq) {
+      if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
+      if (M.best_dist) M.best_dist[qo + q] = res_bd;
     }
-    const int par = q & 1;
-    if (lane == 0) { sRed[par][2 * wid] = best; sRed[par][2 * wid + 1] = second; }
-    __syncthreads();
-    best = sRed[par][0]; second = sRed[par][1];
-#pragma unroll
-    for (int w = 1; w < MATCH_NT / 64; w++) merge2(best, second, sRed[par][2 * w], sRed[par][2 * w + 1]);
-    // decision, identical in every thread
-    int bestDist = 256, bestIdx = -1, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
-    if (best != ~0ull) { bestDist = (int)(best >> 40); bestIdx = (int)((best >> 8) & 0xfffff); bestLevel = (int)(best & 0xff); }
-    if (second != ~0ull) { bestDist2 = (int)(second >> 40); bestLevel2 = (int)(second & 0xff); }
-    bool accept = bestIdx >= 0 && bestDist <= M.th_dist;
-    if (accept && M.use_second && bestLevel == bestLevel2 && (float)bestDist > M.nnratio * (float)bestDist2) accept = false;
-    if (accept) {
-      nmatches++;
-      if ((bestIdx % MATCH_NT) == tid) {
-        const int j = bestIdx / MATCH_NT;
-        const uint32_t ob = (fl >> 1) & 1u;
-        claimed = (claimed & ~(1u << j)) | (ob << j);
-        slot[bestIdx] = q;
-        slot_obs[bestIdx] = (uint8_t)ob;
-      }
-    }
-    if (tid == 0) {
-      if (M.match_of_query) M.match_of_query[qo + q] = accept ? bestIdx : -1;
-      if (M.best_dist) M.best_dist[qo + q] = live ? bestDist : 256;
-    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+    const int32_t v = sSlot[i];
+    if (v >= 0) { slot[i] = v & 0x3fffffff; slot_obs[i] = (uint8_t)((v >> 30) & 1); }
   }
   if (tid == 0 && M.nmatches) M.nmatches[p] = nmatches;
 }

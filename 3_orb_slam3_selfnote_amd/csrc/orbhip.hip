@@ -264,8 +264,8 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
     G.scale = h->mvScaleFactor[l];
     G.kpsize = (float)(int)((float)ORB_PATCH_SIZE * h->mvScaleFactor[l]);  // :862
     // blur tiles
-    G.tilesX = (G.w + 63) / 64;
-    G.tilesY = (G.h + 15) / 16;
+    G.tilesX = (G.w + BLUR_TX - 1) / BLUR_TX;
+    G.tilesY = (G.h + BLUR_TY - 1) / BLUR_TY;
     G.tileBase = tiles;
     tiles += G.tilesX * G.tilesY;
     // resize tables, SURVEY.md A.3 (cv::resize -> hal::resize: scale = 1./(dsize/ssize))
@@ -539,7 +539,7 @@ int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, i
 struct orbm_handle {
   int device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c;
+  DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   bool profiling = false;
   hipEvent_t ev[2] = {};
   bool ev_ok = false, ms_valid = false;
@@ -554,11 +554,6 @@ struct orbm_handle {
       return ORBX_E_HIP;                                                                      \
     }                                                                                         \
   } while (0)
-
-template <int CPT>
-static void launch_search(const MatchProblemSet &M, int npairs, hipStream_t s) {
-  hipLaunchKernelGGL(k_search_by_projection<CPT>, dim3(npairs), dim3(MATCH_NT), 0, s, M);
-}
 
 extern "C" {
 
@@ -577,7 +572,7 @@ void orbm_destroy(orbm_t *m) {
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
-                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c};
+                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk};
   for (DevBuf *b : bufs) b->release();
   if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -673,14 +668,36 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
   const int maxn = d_frame_n ? frame_stride : f->n;
-  if (maxn > 32 * MATCH_NT) { m->err = "more than 8192 keypoints per frame not supported by the search kernel"; return ORBX_E_ARG; }
+  const int maxq = d_query_n ? query_stride : q->nq;
+  if (maxn > 32768) { m->err = "more than 32768 keypoints per frame not supported by the search kernels"; return ORBX_E_ARG; }
+  if (maxn <= 0 || maxq <= 0) return ORBX_E_ARG;
+  // scratch: TOPK keys per query (grows on demand; not on the steady-state path)
+  const bool k32 = maxn <= 2048;  // Key32 holds an 11-bit keypoint index
+  const size_t need = (k32 ? sizeof(uint32_t) : sizeof(unsigned long long)) * MATCH_TOPK * ((size_t)(npairs - 1) * query_stride + maxq);
+  if (need > m->d_topk.bytes) {
+    MCHECK(m, hipStreamSynchronize(s));
+    MCHECK(m, m->d_topk.reserve(need));
+  }
   const bool prof = m->profiling && m->ev_ok;
   m->ms_valid = false;
   if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
-  if (maxn <= 5 * MATCH_NT) launch_search<5>(M, npairs, s);
-  else if (maxn <= 8 * MATCH_NT) launch_search<8>(M, npairs, s);
-  else if (maxn <= 16 * MATCH_NT) launch_search<16>(M, npairs, s);
-  else launch_search<32>(M, npairs, s);
+  const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
+  const size_t small = sizeof(uint32_t) * (size_t)((((maxn + 63) / 64) * 2 + 2) * RESOLVE_NW + maxn + 2);
+  const size_t big = small + 48 * (size_t)maxn;
+  const bool ldscand = big <= 150 * 1024;
+  const size_t lds = ldscand ? big : small;
+  const dim3 rblock(64 * RESOLVE_NW);
+#define LAUNCH_MATCH(KT, LC)                                                                                              \
+  do {                                                                                                                    \
+    if (lds > 48 * 1024)                                                                                                  \
+      MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    hipLaunchKernelGGL(k_match_scan<KT>, sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                           \
+    hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);     \
+  } while (0)
+  if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
+  else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
+#undef LAUNCH_MATCH
   if (prof) { MCHECK(m, hipEventRecord(m->ev[1], s)); m->ms_valid = true; }
   MCHECK(m, hipGetLastError());
   return 0;

@@ -152,7 +152,8 @@ typedef struct {
  * use_second != 0: best/second-best with the same-level ratio test of ORBmatcher.cc:104-129 (M2);
  * use_second == 0: strict-less argmin with threshold th_dist (M3 :2152-2162, M4 :2362-2371, M5 :586-600).
  * slot[n] (in/out): query id holding keypoint i, -1 = free (F.mvpMapPoints); slot_obs[n] (in/out): 1 if that
- * holder has Observations()>0.  match_of_query[nq], best_dist[nq] (out, may be NULL).
+ * holder has Observations()>0.  match_of_query[nq] (out, may be NULL); best_dist[nq] (out, may be NULL) = distance
+ * of the best unclaimed candidate when it is <= th_dist, else 256.
  * Queries are resolved in index order with the reference's sequential claim semantics.  Returns nmatches. */
 int orbm_search_by_projection(orbm_t *m, const orbm_frame_t *frame, const orbm_queries_t *q, float nnratio,
                               int th_dist, int use_second, int32_t *slot, uint8_t *slot_obs,

@@ -913,7 +913,7 @@ int orc_search_by_projection_win(orc_frame *f, int nq, const uint8_t *in_view, c
         bestDist2 = dist;
       }
     }
-    if (best_dist_out) best_dist_out[q] = bestDist;
+    if (best_dist_out) best_dist_out[q] = bestDist <= th_high ? bestDist : 256; /* distance of the best candidate if within the threshold */
     if (bestDist <= th_high) {
       if (mode_second && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
       slot[bestIdx] = q;

@@ -78,11 +78,12 @@ def test_search_stress_1000x1000(pkg, oracle, synth, matcher):
     assert np.array_equal(F.slot, OF.slot)
 
 
-def test_claims_and_ties(pkg, oracle, matcher):
+@pytest.mark.parametrize("N", [600, 4000])
+def test_claims_and_ties(pkg, oracle, matcher, N):
     """Collisions: duplicated descriptors (distance ties decided by grid-walk order), duplicated queries (later
-    queries lose a claimed keypoint only if the holder has observations), pre-occupied slots."""
+    queries lose a claimed keypoint only if the holder has observations), pre-occupied slots.
+    N = 4000 exceeds the LDS-resident candidate copy of the resolve kernel (global-memory rescan path)."""
     rng = np.random.default_rng(11)
-    N = 600
     kps = np.zeros(N, dtype=pkg.KP_DTYPE)
     kps["x"] = rng.uniform(5, 747, N).astype(np.float32)
     kps["y"] = rng.uniform(5, 475, N).astype(np.float32)
