@@ -86,39 +86,82 @@ __device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
 // Thread = 4 consecutive output pixels (one 32-bit store); block = 64x4 threads = 256x4 output pixels.
 // Tables {sx, a0|a1<<16} / {sy, b0|b1<<16} are built on the host (orbx_configure).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level) {
+// One level of every frame.  Workgroup = RESIZE_ROWS output rows x full width: the <= 1.2*RESIZE_ROWS+2 source rows
+// it needs are staged in LDS with coalesced dword loads (plus the x coefficient table), so the 16 byte gathers per
+// output quad hit LDS instead of issuing 16 global byte loads (the first version was load-issue bound).
+#define RESIZE_ROWS 8
+#define RESIZE_MAXSRC 16   // source rows per tile: floor(1.2*(RESIZE_ROWS-1)) + 2 with margin (scale <= 1.6 supported)
+__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes) {
+  extern __shared__ __align__(16) uint8_t smem_rs[];
   const LevelGeom G = P.geom[level];
   const LevelGeom Gs = P.geom[level - 1];
-  const int frame = blockIdx.z;
-  const int dy = blockIdx.y * 4 + threadIdx.y;
-  const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  if (dy >= G.h || dx0 >= G.w) return;
+  const int frame = blockIdx.y, tid = threadIdx.x;
+  const int dy0 = blockIdx.x * RESIZE_ROWS;
+  const int nrows = min(RESIZE_ROWS, G.h - dy0);
   int spitch;
   const uint8_t *src = level_plane(P, frame, level - 1, spitch);
-  uint8_t *dst = P.pyr + (size_t)frame * P.pyr_fs + G.off + (size_t)dy * G.pitch;
-  const int2 yt = P.ytab[G.ytabBase + dy];
-  int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
-  const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
-  const uint8_t *S0 = src + (size_t)sy0 * spitch, *S1 = src + (size_t)sy1 * spitch;
-  uint32_t packed = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int dx = dx0 + j;
-    if (dx < G.w) {
-      const int2 xt = P.xtab[G.xtabBase + dx];
-      const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
-      const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
-      const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-      const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-      int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-      v = min(max(v, 0), 255);
-      packed |= (uint32_t)v << (8 * j);
+  // source row span of this tile
+  const int syFirst = min(max(P.ytab[G.ytabBase + dy0].x, 0), Gs.h - 1);
+  const int syLast = min(max(P.ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), Gs.h - 1);
+  const int nsrc = syLast - syFirst + 1;
+  int2 *sX = reinterpret_cast<int2 *>(smem_rs);                       // [G.w]
+  uint8_t *sRows = smem_rs + (((size_t)G.w * 8 + 15) & ~(size_t)15);   // [nsrc][smemRowBytes]
+  for (int i = tid; i < G.w; i += 256) sX[i] = P.xtab[G.xtabBase + i];
+  const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
+  if (nsrc <= RESIZE_MAXSRC) {
+    if (aligned) {
+      const int ndw = (Gs.w + 3) >> 2;  // the last dword may read up to 3 bytes of row padding / next row: inside the plane
+      const bool lastRowPartial = (Gs.w & 3) != 0;
+      const uint32_t mg = 0xffffffffu / (uint32_t)ndw + 1u;
+      for (int idx = tid; idx < ndw * nsrc; idx += 256) {
+        const int r = (int)__umulhi((uint32_t)idx, mg), d = idx - r * ndw;
+        const uint8_t *rowp = src + (size_t)(syFirst + r) * spitch;
+        uint32_t v;
+        if (lastRowPartial && d == ndw - 1 && syFirst + r == Gs.h - 1 && spitch < 4 * ndw) {
+          v = 0;  // very last bytes of the plane: do not read past the allocation
+          for (int b = 0; 4 * d + b < Gs.w; b++) v |= (uint32_t)rowp[4 * d + b] << (8 * b);
+        } else {
+          v = *reinterpret_cast<const uint32_t *>(rowp + 4 * d);
+        }
+        *reinterpret_cast<uint32_t *>(sRows + (size_t)r * smemRowBytes + 4 * d) = v;
+      }
+    } else {
+      for (int idx = tid; idx < Gs.w * nsrc; idx += 256) {
+        const int r = idx / Gs.w, c = idx - r * Gs.w;
+        sRows[(size_t)r * smemRowBytes + c] = src[(size_t)(syFirst + r) * spitch + c];
+      }
     }
   }
-  if (dx0 + 3 < G.w) {
-    *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
-  } else {
-    for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
+  __syncthreads();
+  uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
+  const int qw = (G.w + 3) >> 2;
+  const uint32_t mq = 0xffffffffu / (uint32_t)qw + 1u;
+  for (int q = tid; q < qw * nrows; q += 256) {
+    const int ry = (int)__umulhi((uint32_t)q, mq), dx0 = (q - ry * qw) * 4, dy = dy0 + ry;
+    const int2 yt = P.ytab[G.ytabBase + dy];
+    const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
+    const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+    const uint8_t *S0, *S1;
+    if (nsrc <= RESIZE_MAXSRC) { S0 = sRows + (size_t)(sy0 - syFirst) * smemRowBytes; S1 = sRows + (size_t)(sy1 - syFirst) * smemRowBytes; }
+    else { S0 = src + (size_t)sy0 * spitch; S1 = src + (size_t)sy1 * spitch; }  // extreme scale factors: straight from global
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int dx = dx0 + j;
+      if (dx < G.w) {
+        const int2 xt = sX[dx];
+        const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+        const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        packed |= (uint32_t)v << (8 * j);
+      }
+    }
+    uint8_t *dst = dstplane + (size_t)dy * G.pitch;
+    if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
+    else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
   }
 }
 

@@ -238,18 +238,20 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
   return (acc ? 0x80000000u : 0u) | (rescan ? 0x40000000u : 0u) | (found > 0 ? (uint32_t)KT::idx(best) : 0u);
 }
 
-// One workgroup (RESOLVE_NW wavefronts) per problem, queries in order.  EVERY wave replays the same sequential turn
-// loop on its own private copy of the claim bitmap (bits only ever go 0 -> 1, the loop is deterministic, so the
-// copies never diverge and no per-turn barrier is needed); the waves only meet in a rescan, where they split the
-// keypoints and exchange their partial (best, second) through LDS.  Wave 0 also records the new slot holders.
-// Each lane owns one query of the current 64-query chunk and keeps its decision current: a turn = one readlane of
-// lane i's decision, the claim, and a re-decide in the lanes whose lists contain the claimed keypoint.
+// One workgroup (RESOLVE_NW wavefronts) per problem, queries in order.
+// Wave 0 runs the sequential turn loop alone: each lane owns one query of the current 64-query chunk and keeps its
+// decision current; a turn = one readlane of lane i's decision, the claim, and a re-decide in the lanes whose lists
+// contain the claimed keypoint.  The other waves sleep in s_barrier and are woken only for a rescan, where all waves
+// split the keypoints and exchange their partial (best, second) through LDS (command word: query index, or -1 = exit).
+// LDS: sClaim = one bit per keypoint ("held by a map point with observations"; bits only go 0 -> 1),
+//      sSlot  = the new holder of each keypoint (query | obs<<30, or -1).
 // LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that rescans never leave the CU.
 template <typename KT, bool LDSCAND>
 __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
-  __shared__ K sPart[2][RESOLVE_NW][2];
+  __shared__ K sPart[RESOLVE_NW][2];
+  __shared__ int sCmd;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -259,14 +261,14 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
   int32_t *slot = M.slot + fo;
   uint8_t *slot_obs = M.slot_obs + fo;
-  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [RESOLVE_NW claim bitmaps][slot]
+  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [claim bitmap][slot]
   const int cwords = ((maxn + 63) >> 6) * 2 + 2;
   uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
   CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
   uint32_t *rest = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
-  volatile uint32_t *sClaim = rest + (size_t)wid * cwords;  // this wave's private copy
-  volatile int32_t *sSlot = reinterpret_cast<volatile int32_t *>(rest + (size_t)RESOLVE_NW * cwords);
-  for (int b0 = 0; b0 < n; b0 += 64) {
+  volatile uint32_t *sClaim = rest;
+  volatile int32_t *sSlot = reinterpret_cast<volatile int32_t *>(rest + cwords);
+  for (int b0 = wid * 64; b0 < n; b0 += 64 * RESOLVE_NW) {
     const int i = b0 + lane;
     const bool cl = i < n && slot[i] >= 0 && slot_obs[i];
     const unsigned long long mask = __ballot(cl);
@@ -290,122 +292,136 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     if (LDSCAND) return (int)(sMeta[idx].bits & 0xff);
     return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
   };
-  int nmatches = 0, nrescan = 0;
-  for (int base = 0; base < nq; base += 64) {
-    const int q = base + lane;
-    K tk[MATCH_TOPK];
-    uint32_t cm = 0, oct4 = 0;  // bit j: entry j of my list is claimed; 4 bits per entry: its octave
+  // this wave's share of an exact rescan of query qq with the current claims -> sPart[wid]
+  auto rescan_part = [&](int qq) {
+    const QueryWin w = load_query(M, qo, qq);
+    const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + qq) * 32);
+    K b1 = KT::NONE, b2 = KT::NONE;
+    if (w.live) {
+      uint32_t q8[8];
 #pragma unroll
-    for (int j = 0; j < MATCH_TOPK; j++) {
-      tk[j] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
-      if (tk[j] != KT::NONE) {
-        const int idx = KT::idx(tk[j]);
-        cm |= ((sClaim[idx >> 5] >> (idx & 31)) & 1u) << j;
-        oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
+      for (int t = 0; t < 8; t++) q8[t] = qd[t];
+      for (int c = tid; c < n; c += 64 * RESOLVE_NW) {
+        const bool cl = (sClaim[c >> 5] >> (c & 31)) & 1u;
+        float x, y, cur;
+        uint32_t bits, d8[8];
+        if (LDSCAND) {
+          const CandMeta cmeta = sMeta[c];
+          x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
+          bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
+          const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+          d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
+        } else {
+          x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
+          bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
+          cur = M.u_right ? M.u_right[fo + c] : -1.f;
+#pragma unroll
+          for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
+        }
+        if (cand_passes(w, x, y, bits, cur)) {
+          int dist = 0;
+#pragma unroll
+          for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
+          const K key = KT::make(dist, cell_of(bits), c);
+          if (key < b1) { b2 = b1; b1 = key; }
+          else if (key < b2) b2 = key;
+        }
       }
     }
-    const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
-    int my_bd;
-    uint32_t D = decide<KT>(M, tk, cm, oct4, &my_bd);
-    int res_idx = -1, res_bd = 256;
-    const int cnt = min(64, nq - base);
-    for (int i = 0; i < cnt; i++) {
-      const uint32_t Di = (uint32_t)__builtin_amdgcn_readlane((int)D, i);
-      const uint32_t ob = ((uint32_t)__builtin_amdgcn_readlane((int)myfl, i) >> 1) & 1u;
-      bool accept = (Di >> 31) & 1u;
-      int bestIdx = (int)(Di & 0xfffff);
-      if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
-      if ((Di >> 30) & 1u) {
-        // exact rescan of this query over all keypoints with the current claims; the waves split the keypoints
-        const int qq = base + i;
-        const QueryWin w = load_query(M, qo, qq);
-        const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + qq) * 32);
-        K b1 = KT::NONE, b2 = KT::NONE;
-        if (w.live) {
-          uint32_t q8[8];
+    // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
+    K m1 = b1;
 #pragma unroll
-          for (int t = 0; t < 8; t++) q8[t] = qd[t];
-          for (int c = tid; c < n; c += 64 * RESOLVE_NW) {
-            const bool cl = (sClaim[c >> 5] >> (c & 31)) & 1u;
-            float x, y, cur;
-            uint32_t bits, d8[8];
-            if (LDSCAND) {
-              const CandMeta cmeta = sMeta[c];
-              x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
-              bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
-              const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-              d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
-            } else {
-              x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
-              bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
-              cur = M.u_right ? M.u_right[fo + c] : -1.f;
+    for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m1, o); m1 = t < m1 ? t : m1; }
+    K m2 = (b1 == m1) ? b2 : b1;
 #pragma unroll
-              for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
-            }
-            if (cand_passes(w, x, y, bits, cur)) {
-              int dist = 0;
+    for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m2, o); m2 = t < m2 ? t : m2; }
+    if (lane == 0) { sPart[wid][0] = m1; sPart[wid][1] = m2; }
+  };
+
+  if (wid != 0) {
+    // helper waves: sleep at the barrier until wave 0 posts a command
+    for (;;) {
+      __syncthreads();                 // (A) command posted
+      const int cmd = sCmd;
+      if (cmd < 0) break;
+      rescan_part(cmd);
+      __syncthreads();                 // (B) partials posted
+    }
+  } else {
+    int nmatches = 0;
+    for (int base = 0; base < nq; base += 64) {
+      const int q = base + lane;
+      K tk[MATCH_TOPK];
+      uint32_t cm = 0, oct4 = 0;  // bit j: entry j of my list is claimed; 4 bits per entry: its octave
 #pragma unroll
-              for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
-              const K key = KT::make(dist, cell_of(bits), c);
-              if (key < b1) { b2 = b1; b1 = key; }
-              else if (key < b2) b2 = key;
-            }
+      for (int j = 0; j < MATCH_TOPK; j++) {
+        tk[j] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+        if (tk[j] != KT::NONE) {
+          const int idx = KT::idx(tk[j]);
+          cm |= ((sClaim[idx >> 5] >> (idx & 31)) & 1u) << j;
+          oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
+        }
+      }
+      const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
+      int my_bd;
+      uint32_t D = decide<KT>(M, tk, cm, oct4, &my_bd);
+      int res_idx = -1, res_bd = 256;
+      const int cnt = min(64, nq - base);
+      for (int i = 0; i < cnt; i++) {
+        const uint32_t Di = (uint32_t)__builtin_amdgcn_readlane((int)D, i);
+        const uint32_t ob = ((uint32_t)__builtin_amdgcn_readlane((int)myfl, i) >> 1) & 1u;
+        bool accept = (Di >> 31) & 1u;
+        int bestIdx = (int)(Di & 0xfffff);
+        if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
+        if ((Di >> 30) & 1u) {
+          if (lane == 0) sCmd = base + i;
+          __syncthreads();             // (A)
+          rescan_part(base + i);
+          __syncthreads();             // (B)
+          K g1 = KT::NONE, g2 = KT::NONE;
+#pragma unroll
+          for (int ww = 0; ww < RESOLVE_NW; ww++) {
+            const K a1 = sPart[ww][0], a2 = sPart[ww][1];
+            const K nb = g1 < a1 ? g1 : a1;
+            const K mx = g1 < a1 ? a1 : g1;
+            const K ms = g2 < a2 ? g2 : a2;
+            g2 = mx < ms ? mx : ms;
+            g1 = nb;
+          }
+          const bool has1 = g1 != KT::NONE, has2 = g2 != KT::NONE;
+          const int bd = has1 ? KT::dist(g1) : 256;
+          bestIdx = has1 ? KT::idx(g1) : 0;
+          accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
+          if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; }
+        }
+        if (accept) {
+          nmatches++;
+          if (lane == 0) {
+            if (ob) sClaim[bestIdx >> 5] = sClaim[bestIdx >> 5] | (1u << (bestIdx & 31));
+            sSlot[bestIdx] = (int32_t)((uint32_t)(base + i) | (ob << 30));
+          }
+          if (ob) {  // lanes whose list contains the claimed keypoint re-decide
+            uint32_t ncm = cm;
+#pragma unroll
+            for (int j = 0; j < MATCH_TOPK; j++)
+              if (tk[j] != KT::NONE && KT::idx(tk[j]) == bestIdx) ncm |= 1u << j;
+            if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
           }
         }
-        // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
-        K m1 = b1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m1, o); m1 = t < m1 ? t : m1; }
-        K m2 = (b1 == m1) ? b2 : b1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m2, o); m2 = t < m2 ? t : m2; }
-        const int par = nrescan & 1;
-        nrescan++;
-        if (lane == 0) { sPart[par][wid][0] = m1; sPart[par][wid][1] = m2; }
-        __syncthreads();
-        K g1 = KT::NONE, g2 = KT::NONE;
-#pragma unroll
-        for (int ww = 0; ww < RESOLVE_NW; ww++) {
-          const K a1 = sPart[par][ww][0], a2 = sPart[par][ww][1];
-          // merge (g1<=g2) with (a1<=a2)
-          const K nb = g1 < a1 ? g1 : a1;
-          const K mx = g1 < a1 ? a1 : g1;
-          const K ms = g2 < a2 ? g2 : a2;
-          g2 = mx < ms ? mx : ms;
-          g1 = nb;
-        }
-        const bool has1 = g1 != KT::NONE, has2 = g2 != KT::NONE;
-        const int bd = has1 ? KT::dist(g1) : 256;
-        bestIdx = has1 ? KT::idx(g1) : 0;
-        accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
-        if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; }
       }
-      if (accept) {
-        nmatches++;
-        if (lane == 0) {
-          if (ob) sClaim[bestIdx >> 5] = sClaim[bestIdx >> 5] | (1u << (bestIdx & 31));
-          if (wid == 0) sSlot[bestIdx] = (int32_t)((uint32_t)(base + i) | (ob << 30));
-        }
-        if (ob) {  // lanes whose list contains the claimed keypoint re-decide
-          uint32_t ncm = cm;
-#pragma unroll
-          for (int j = 0; j < MATCH_TOPK; j++)
-            if (tk[j] != KT::NONE && KT::idx(tk[j]) == bestIdx) ncm |= 1u << j;
-          if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
-        }
+      if (q < nq) {
+        if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
+        if (M.best_dist) M.best_dist[qo + q] = res_bd;
       }
     }
-    if (wid == 0 && q < nq) {
-      if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
-      if (M.best_dist) M.best_dist[qo + q] = res_bd;
-    }
+    if (lane == 0) { sCmd = -1; if (M.nmatches) M.nmatches[p] = nmatches; }
+    __syncthreads();                   // (A) exit command
   }
-  __syncthreads();
+  __syncthreads();                     // sSlot complete
   for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
     const int32_t v = sSlot[i];
     if (v >= 0) { slot[i] = v & 0x3fffffff; slot_obs[i] = (uint8_t)((v >> 30) & 1); }
   }
-  if (tid == 0 && M.nmatches) M.nmatches[p] = nmatches;
 }
 
 // K8 brute force: dist[i][j] = popcount(q_i ^ c_j).  Candidates staged through LDS in 256-descriptor (8 KB) chunks.

@@ -407,9 +407,11 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   h->stage_valid = false;
   if (prof) XCHECK(h, hipEventRecord(h->ev[0], s));
   for (int l = 1; l < h->nlevels; l++) {
-    const LevelGeom &G = h->geom[l];
-    dim3 grid((G.w + 255) / 256, (G.h + 3) / 4, nframes), block(64, 4, 1);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, s, P, l);
+    const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
+    const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
+    const size_t lds = align_up((size_t)G.w * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;
+    if (lds > 48 * 1024) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_resize, dim3((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, nframes), dim3(256), lds, s, P, l, rowBytes);
   }
   if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells, nframes), dim3(256), 0, s, P);
@@ -682,7 +684,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   m->ms_valid = false;
   if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
-  const size_t small = sizeof(uint32_t) * (size_t)((((maxn + 63) / 64) * 2 + 2) * RESOLVE_NW + maxn + 2);
+  const size_t small = sizeof(uint32_t) * (size_t)((((maxn + 63) / 64) * 2 + 2) + maxn + 2);
   const size_t big = small + 48 * (size_t)maxn;
   const bool ldscand = big <= 150 * 1024;
   const size_t lds = ldscand ? big : small;
