@@ -15,9 +15,27 @@
 
 #define WAVE 64
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "../../include/orb_pattern_data.inc"
 };
+
+// Offsets (u, v) of the 749 pixels of the radius-15 intensity-centroid disc, rows v = -15..15, u = -umax[|v|]..umax[|v|]
+// (ORBextractor.cc:452-467 always yields umax = 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 for HALF_PATCH_SIZE 15;
+// orbx_create re-derives umax at run time and refuses to start if it differs).  Padded to 768 with (0,0), which
+// contributes u*I = v*I = 0 to the moments.
+struct DiscTab { int8_t u[768]; int8_t v[768]; };
+constexpr DiscTab make_disc_tab() {
+  DiscTab t{};
+  const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  int n = 0;
+  for (int v = -15; v <= 15; v++) {
+    const int d = umax[v < 0 ? -v : v];
+    for (int u = -d; u <= d; u++) { t.u[n] = (int8_t)u; t.v[n] = (int8_t)v; n++; }
+  }
+  for (; n < 768; n++) { t.u[n] = 0; t.v[n] = 0; }
+  return t;
+}
+__constant__ DiscTab c_disc = make_disc_tab();
 
 // ------------------------------------------------------------------------------------------------------------
 // small helpers
@@ -302,10 +320,11 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
     const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
     const int S = s[0];
-    bool keep = false;
-    if (S > tmin && S >= 2)
-      keep = S > s[-1] && S > s[1] && S > s[-FAST_S_PITCH - 1] && S > s[-FAST_S_PITCH] && S > s[-FAST_S_PITCH + 1] &&
-             S > s[FAST_S_PITCH - 1] && S > s[FAST_S_PITCH] && S > s[FAST_S_PITCH + 1];
+    // branch-free: strict maximum <=> S > max of the 8 neighbours (v_max3 chain, no exec-mask juggling)
+    const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
+    const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
+    const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
+    const bool keep = (S > tmin) & (S >= 2) & (S > m2);
     sM[p] = keep ? (uint8_t)S : 0;
     myIni += (keep && S > P.iniTh) ? 1u : 0u;
   }
@@ -773,17 +792,18 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const int X = (int)(packed & 0xfff) + ORB_MIN_BORDER, Y = (int)((packed >> 12) & 0xfff) + ORB_MIN_BORDER;
   const int dst = (rk & 0x8000u) ? nTot - 1 - (lapBefore + (int)(rk & 0x7fff)) : monoBefore + (int)(rk & 0x7fff);
 
-  // IC_Angle on the unblurred level
+  // IC_Angle on the unblurred level: 12 independent gathers per lane, all in flight together
   int pitch;
   const uint8_t *img = level_plane(P, frame, level, pitch);
   const uint8_t *centre = img + (size_t)Y * pitch + X;
   int m10 = 0, m01 = 0;
-  for (int e = lane; e < ORB_DISC_PIXELS; e += 64) {
-    int u = P.disc[2 * e], v = P.disc[2 * e + 1];
-    int val = centre[v * pitch + u];
-    m10 += u * val;
-    m01 += v * val;
-  }
+  int dv[12], du[12], dval[12];
+#pragma unroll
+  for (int t = 0; t < 12; t++) { du[t] = c_disc.u[t * 64 + lane]; dv[t] = c_disc.v[t * 64 + lane]; }
+#pragma unroll
+  for (int t = 0; t < 12; t++) dval[t] = centre[dv[t] * pitch + du[t]];
+#pragma unroll
+  for (int t = 0; t < 12; t++) { m10 += du[t] * dval[t]; m01 += dv[t] * dval[t]; }
   m10 = wave_sum_i32(m10);
   m01 = wave_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -795,15 +815,20 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const uint8_t *bc = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)Y * G.bpitch + X;
   const int bp = G.bpitch;
   unsigned long long bits[4];
+  int o0[4], o1[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int t = r * 64 + lane;
-    const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
-    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
-    const int v0 = bc[__float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b)];
-    const int v1 = bc[__float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b)];
-    bits[r] = __ballot(v0 < v1);
+    const uint32_t pw = reinterpret_cast<const uint32_t *>(c_pattern)[r * 64 + lane];  // x0, y0, x1, y1 as int8
+    const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
+    o0[r] = __float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b);
+    o1[r] = __float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b);
   }
+  int v0[4], v1[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { v0[r] = bc[o0[r]]; v1[r] = bc[o1[r]]; }
+#pragma unroll
+  for (int r = 0; r < 4; r++) bits[r] = __ballot(v0[r] < v1[r]);
   if (dst < P.cap) {
     uint32_t *dd = reinterpret_cast<uint32_t *>(P.out_desc + ((size_t)frame * P.cap + dst) * 32);
     if (lane < 8) {

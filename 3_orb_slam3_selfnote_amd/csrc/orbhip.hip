@@ -154,6 +154,11 @@ orbx_t *orbx_create(int nfeatures, float scaleFactor_, int nlevels, int iniThFAS
     for (int u = -d; u <= d; u++) { disc.push_back((int8_t)u); disc.push_back((int8_t)v); }
   }
   if ((int)disc.size() != 2 * ORB_DISC_PIXELS) { delete h; return nullptr; }
+  {
+    const DiscTab ref = make_disc_tab();  // the kernels' compile-time table must equal what ORBextractor.cc:452-467 derives
+    for (int i = 0; i < ORB_DISC_PIXELS; i++)
+      if (ref.u[i] != disc[2 * i] || ref.v[i] != disc[2 * i + 1]) { delete h; return nullptr; }
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
   if (h->d_disc.reserve(disc.size()) != hipSuccess ||
       hipMemcpy(h->d_disc.p, disc.data(), disc.size(), hipMemcpyHostToDevice) != hipSuccess) {

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=3, help="independent pipelines on separate HIP streams (steps alternate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1])")
     args = ap.parse_args()
@@ -101,51 +102,69 @@ def main():
 
     B = args.batch
     frames, offs = synth.make_stream(1000 + rank, B, H, W)          # B distinct frames of one moving scene
-    ex = pkg.ORBextractor(device=local_rank, **CFG)
-    mt = pkg.ORBmatcher(0.8, True, device=local_rank)
-    cap = ex.configure(H, W, B)
-    level_shapes = [ex.level_shape(l) for l in range(CFG["nlevels"])]
-
     d_img = torch.from_numpy(frames).to(dev)                         # inputs resident in HBM before timing starts
-    # slot 0 = last frame of the previous step (query side of pair 0); slots 1..B = this step's frames
-    d_kps = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros((B + 1, 2), dtype=torch.int32, device=dev)
     # shift of the scene between frame t-1 and t (pair p: queries = slot p, candidates = slot p+1)
     shift = np.zeros((B, 2), dtype=np.float32)
     for p in range(B):
         prev = offs[p - 1] if p > 0 else offs[B - 1]
         shift[p] = (prev[0] - offs[p][0], prev[1] - offs[p][1])
     d_shift = torch.from_numpy(shift).to(dev)
-    d_radius = torch.full((B, cap), 1.0e4, dtype=torch.float32, device=dev)
-    d_lvl = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
-    d_slot = torch.empty((B, cap), dtype=torch.int32, device=dev)
-    d_sobs = torch.empty((B, cap), dtype=torch.uint8, device=dev)
-    d_moq = torch.empty((B, cap), dtype=torch.int32, device=dev)
-    d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    kp1 = d_kps[1:]
-    fs = pkg.FrameStruct(cap, kp1.data_ptr(), d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
     C = pkg.C
 
+    class Pipe:
+        """One independent extract+match pipeline: its own handles, workspace, outputs and HIP stream.  Consecutive steps
+        alternate between args.streams pipelines so that the latency-bound kernels of one step (octree, in-order match
+        resolve) overlap the throughput-bound kernels of the next (separate HIP streams, no dependency between steps)."""
+
+        def __init__(self):
+            self.ex = pkg.ORBextractor(device=local_rank, **CFG)
+            self.mt = pkg.ORBmatcher(0.8, True, device=local_rank)
+            self.cap = cap = self.ex.configure(H, W, B)
+            self.stream = torch.cuda.Stream(device=dev)
+            # slot 0 = last frame of the previous step (query side of pair 0); slots 1..B = this step's frames
+            self.d_kps = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
+            self.d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+            self.d_cnt = torch.zeros((B + 1, 2), dtype=torch.int32, device=dev)
+            self.d_radius = torch.full((B, cap), 1.0e4, dtype=torch.float32, device=dev)
+            self.d_lvl = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+            self.d_slot = torch.empty((B, cap), dtype=torch.int32, device=dev)
+            self.d_sobs = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+            self.d_moq = torch.empty((B, cap), dtype=torch.int32, device=dev)
+            self.d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.kp1 = self.d_kps[1:]
+            self.fs = pkg.FrameStruct(cap, self.kp1.data_ptr(), self.d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
+
+        def step(self):
+            cap, ex, mt = self.cap, self.ex, self.mt
+            d_kps, d_desc, d_cnt = self.d_kps, self.d_desc, self.d_cnt
+            with torch.cuda.stream(self.stream):
+                stream = self.stream.cuda_stream
+                # carry the last frame of the previous pass into slot 0 (60 KB device copy)
+                d_kps[0].copy_(d_kps[B]); d_desc[0].copy_(d_desc[B]); d_cnt[0].copy_(d_cnt[B])
+                ex.extract_batch_device(d_img.data_ptr(), H, W, W, H * W, B, self.kp1.data_ptr(), d_desc[1:].data_ptr(), d_cnt[1:].data_ptr(), cap, LAP, stream=stream)
+                if args.no_match:
+                    return
+                # caller-side projection of the previous frame's features into the current frame (pure shift in this stream)
+                u = (d_kps[:B, :, 0] + d_shift[:, 0:1]).contiguous()
+                v = (d_kps[:B, :, 1] + d_shift[:, 1:2]).contiguous()
+                self.d_slot.fill_(-1); self.d_sobs.zero_()                  # Frame ctor: mvpMapPoints = NULL
+                qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), self.d_radius.data_ptr(), self.d_lvl.data_ptr(), self.d_lvl.data_ptr(), None, None)
+                rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(self.fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
+                                                                 C.c_void_p(d_cnt.data_ptr()), 2, B, C.c_float(0.8), 100, 1,
+                                                                 C.c_void_p(self.d_slot.data_ptr()), C.c_void_p(self.d_sobs.data_ptr()), C.c_void_p(self.d_moq.data_ptr()),
+                                                                 None, C.c_void_p(self.d_nm.data_ptr()), C.c_void_p(stream))
+                if rc < 0:
+                    raise RuntimeError("orbm_search_by_projection_batch_device rc=%d %s" % (rc, mt.L.orbm_last_error(mt.m)))
+
+    pipes = [Pipe() for _ in range(max(1, args.streams))]
+    cap = pipes[0].cap
+    level_shapes = [pipes[0].ex.level_shape(l) for l in range(CFG["nlevels"])]
+    torch.cuda.synchronize()
+    counter = [0]
+
     def step():
-        # carry the last frame of the previous pass into slot 0 (60 KB device copy)
-        d_kps[0].copy_(d_kps[B]); d_desc[0].copy_(d_desc[B]); d_cnt[0].copy_(d_cnt[B])
-        ex.extract_batch_device(d_img.data_ptr(), H, W, W, H * W, B, kp1.data_ptr(), d_desc[1:].data_ptr(), d_cnt[1:].data_ptr(), cap, LAP, stream=stream)
-        if args.no_match:
-            return
-        # caller-side projection of the previous frame's features into the current frame (pure shift in this stream)
-        u = (d_kps[:B, :, 0] + d_shift[:, 0:1]).contiguous()
-        v = (d_kps[:B, :, 1] + d_shift[:, 1:2]).contiguous()
-        d_slot.fill_(-1); d_sobs.zero_()                            # Frame ctor: mvpMapPoints = NULL
-        qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), d_radius.data_ptr(), d_lvl.data_ptr(), d_lvl.data_ptr(), None, None)
-        rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
-                                                         C.c_void_p(d_cnt.data_ptr()), 2, B, C.c_float(0.8), 100, 1,
-                                                         C.c_void_p(d_slot.data_ptr()), C.c_void_p(d_sobs.data_ptr()), C.c_void_p(d_moq.data_ptr()),
-                                                         None, C.c_void_p(d_nm.data_ptr()), C.c_void_p(stream))
-        if rc < 0:
-            raise RuntimeError("orbm_search_by_projection_batch_device rc=%d %s" % (rc, mt.L.orbm_last_error(mt.m)))
+        pipes[counter[0] % len(pipes)].step()
+        counter[0] += 1
 
     for _ in range(args.warmup):
         step()
@@ -166,13 +185,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- per-kernel timing pass (HIP events recorded on the launch stream inside liborbhip) ----
+    # ---- per-kernel timing pass (HIP events recorded on the launch stream inside liborbhip; one pipeline, serial) ----
+    ex, mt = pipes[0].ex, pipes[0].mt
     ex.set_profiling(True)
     mt.set_profiling(True)
     acc = {}
     nprof = 5
     for _ in range(nprof):
-        step()
+        pipes[0].step()
         torch.cuda.synchronize()
         st = ex.stage_ms()
         if not args.no_match:
@@ -181,6 +201,7 @@ def main():
             acc[k] = acc.get(k, 0.0) + v / nprof
     ex.set_profiling(False)
     mt.set_profiling(False)
+    d_cnt, d_nm = pipes[0].d_cnt, pipes[0].d_nm
 
     cnt = d_cnt[1:].cpu().numpy()
     n_kp = float(cnt[:, 0].mean())
@@ -203,7 +224,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: extract + SearchByProjection match, 1000x1000 candidates, synthetic frame stream",
-                       "image": "%dx%d" % (W, H), "nfeatures": 1000, "nlevels": 8, "frames_per_step_per_gpu": B,
+                       "image": "%dx%d" % (W, H), "nfeatures": 1000, "nlevels": 8, "frames_per_step_per_gpu": B, "streams": len(pipes),
                        "mean_keypoints_per_frame": round(n_kp, 1), "mean_matches_per_frame": round(float(nm.mean()), 1),
                        "sharding": "frames round-robin, one process per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
