@@ -31,10 +31,10 @@ ABI_SYMBOLS = [
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
-    "orbx_ref_cosf", "orbx_ref_sinf",
+    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_hamming_matrix", "orbm_three_maxima",
-    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms",
+    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
 
@@ -92,6 +92,7 @@ def load(build_if_needed=True):
     L.orbx_download_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
+    L.orbx_calibration_copy.argtypes = [vp, vp, sz, vp]
     L.orbx_ref_cosf.restype = f32
     L.orbx_ref_cosf.argtypes = [f32]
     L.orbx_ref_sinf.restype = f32
@@ -115,6 +116,7 @@ def load(build_if_needed=True):
     L.orbm_set_profiling.argtypes = [vp, i32]
     L.orbm_get_last_ms.restype = f32
     L.orbm_get_last_ms.argtypes = [vp]
+    L.orbm_get_stage_ms.argtypes = [vp, vp, i32]
     _lib = L
     return L
 
@@ -411,6 +413,11 @@ class ORBmatcher:
 
     def last_ms(self):
         return float(self.L.orbm_get_last_ms(self.m))
+
+    def stage_ms(self):
+        ms = np.zeros(2, dtype=np.float32)
+        n = self.L.orbm_get_stage_ms(self.m, _p(ms), 2)
+        return dict(zip(["match_scan", "match_resolve"], ms[:n].tolist()))
 
 
 def project(cam_type, params, X, Y, Z):

@@ -55,6 +55,28 @@ __device__ __forceinline__ const uint8_t *level_plane(const FrameParams &P, int 
   return P.pyr + (size_t)frame * P.pyr_fs + P.geom[level].off;
 }
 
+// XCD-aware block -> (frame, item) mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b lands on XCD
+// b % 8, MI355X_MICROARCH.md "Workgroup dispatch"), and each XCD has its own 4 MiB L2.  All items of frame f are
+// therefore placed on XCD f % 8: neighbouring FAST cells / blur tiles / keypoint patches of one frame share cache
+// lines and halo rows, and with this mapping they are fetched into ONE L2 instead of up to eight.  Placement only
+// affects speed, never results.  Grid: 1-D, nframes * nitems blocks.
+__device__ __forceinline__ void xcd_map(int nitems, int nframes, int &frame, int &item) {
+  const unsigned b = blockIdx.x;
+  const unsigned full = (unsigned)(nframes & ~7);
+  const unsigned nfull = full * (unsigned)nitems;
+  if (b < nfull) {
+    const unsigned x = b & 7u, q = b >> 3;
+    const unsigned g = q / (unsigned)nitems;
+    frame = (int)(x + 8u * g);
+    item = (int)(q - g * (unsigned)nitems);
+  } else {
+    const unsigned r = b - nfull;
+    const unsigned g = r / (unsigned)nitems;
+    frame = (int)(full + g);
+    item = (int)(r - g * (unsigned)nitems);
+  }
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -113,8 +135,10 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   extern __shared__ __align__(16) uint8_t smem_rs[];
   const LevelGeom G = P.geom[level];
   const LevelGeom Gs = P.geom[level - 1];
-  const int frame = blockIdx.y, tid = threadIdx.x;
-  const int dy0 = blockIdx.x * RESIZE_ROWS;
+  const int tid = threadIdx.x;
+  int frame, rowTile;
+  xcd_map((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, P.nframes, frame, rowTile);
+  const int dy0 = rowTile * RESIZE_ROWS;
   const int nrows = min(RESIZE_ROWS, G.h - dy0);
   int spitch;
   const uint8_t *src = level_plane(P, frame, level - 1, spitch);
@@ -243,10 +267,11 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[60 * 60];
-  __shared__ uint32_t sCount, sNList;
-  __shared__ uint32_t sWave[16 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int cellId = blockIdx.x, frame = blockIdx.y;
+  __shared__ uint32_t sKept[1024], sOut[1024];
+  __shared__ uint32_t sCount, sNList, sNKept, sNOut;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int cellId, frame;
+  xcd_map(P.totalCells, P.nframes, frame, cellId);
   int level = 0;
   for (int l = 1; l < P.nlevels; l++)
     if (cellId >= P.geom[l].cellBase) level = l;
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     }
   }
   for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += 256) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
-  if (tid == 0) { sCount = 0; sNList = 0; }
+  if (tid == 0) { sCount = 0; sNList = 0; sNKept = 0; sNOut = 0; }
   __syncthreads();
   const int npx = cw * ch;
   const int tmin = min(P.iniTh, P.minTh);
@@ -313,51 +338,42 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
   }
   __syncthreads();
-  // ---- pass 3: 3x3 strict maximum inside the cell (threshold independent); vote for the iniThFAST set
-  uint8_t *sM = reinterpret_cast<uint8_t *>(sList);  // the work list is dead: reuse it as the kept-score plane
-  uint32_t myIni = 0;
-  for (int p = tid; p < npx; p += 256) {
+  // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list; vote for
+  // the iniThFAST set.  Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
+  for (int e = tid; e < nlist; e += 256) {
+    const int p = sList[e];
     const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
     const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
     const int S = s[0];
-    // branch-free: strict maximum <=> S > max of the 8 neighbours (v_max3 chain, no exec-mask juggling)
     const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
     const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
     const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
     const bool keep = (S > tmin) & (S >= 2) & (S > m2);
-    sM[p] = keep ? (uint8_t)S : 0;
-    myIni += (keep && S > P.iniTh) ? 1u : 0u;
-  }
-  unsigned long long anyv = __ballot(myIni != 0);
-  if (lane == 0 && anyv) atomicOr(&sCount, 1u);
-  __syncthreads();
-  const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, ORBextractor.cc:825-828
-  // ---- pass 4: raster-order compaction: pixel p = k*256 + tid; wave w of iteration k owns pixels [k*256+64w, +64)
-  const int niter = (npx + 255) / 256;
-  for (int k = 0; k < niter; k++) {
-    int p = k * 256 + tid;
-    bool f = p < npx && sM[p] > thr;
-    unsigned long long b = __ballot(f);
-    if (lane == 0) sWave[k * 4 + wid] = (uint32_t)__popcll(b);
-  }
-  __syncthreads();
-  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase + (size_t)c * G.cellCap;
-  uint32_t base = 0;
-  for (int k = 0; k < niter; k++) {
-    int p = k * 256 + tid;
-    bool f = p < npx && sM[p] > thr;
-    unsigned long long b = __ballot(f);
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; w++) woff += sWave[k * 4 + w];
-    if (f) {
-      uint32_t rank = base + woff + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-      const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
-      uint32_t X = (uint32_t)(cj * G.wCell + x + 3), Y = (uint32_t)(ci * G.hCell + y + 3);
-      if (rank < (uint32_t)G.cellCap) slots[rank] = ((uint32_t)(sM[p] - 1) << 24) | (Y << 12) | X;
+    if (keep) {
+      sKept[atomicAdd(&sNKept, 1u)] = (uint32_t)p | ((uint32_t)S << 16);  // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
+      if (S > P.iniTh) sCount = 1;                                        // benign race: every writer stores 1
     }
-    base += sWave[k * 4 + 0] + sWave[k * 4 + 1] + sWave[k * 4 + 2] + sWave[k * 4 + 3];
   }
-  if (tid == 0) *cellCnt = min(base, (uint32_t)G.cellCap);
+  __syncthreads();
+  const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
+  const int nkept = (int)sNKept;
+  for (int e = tid; e < nkept; e += 256) {
+    const uint32_t v = sKept[e];
+    if ((int)(v >> 16) > thr) sOut[atomicAdd(&sNOut, 1u)] = v;
+  }
+  __syncthreads();
+  // ---- pass 4: cv::FAST emits rows ascending, x ascending = ascending p: rank by counting (lists are short)
+  const int nout = (int)sNOut;
+  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase + (size_t)c * G.cellCap;
+  for (int e = tid; e < nout; e += 256) {
+    const uint32_t v = sOut[e], p = v & 0xffffu;
+    uint32_t rank = 0;
+    for (int i = 0; i < nout; i++) rank += ((sOut[i] & 0xffffu) < p) ? 1u : 0u;
+    const int y = (int)__umulhi(p, magicw), x = (int)p - y * cw;
+    const uint32_t X = (uint32_t)(cj * G.wCell + x + 3), Y = (uint32_t)(ci * G.hCell + y + 3);
+    if (rank < (uint32_t)G.cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
+  }
+  if (tid == 0) *cellCnt = min((uint32_t)nout, (uint32_t)G.cellCap);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -670,7 +686,8 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   __shared__ uint32_t sIn[38 * 34];
   __shared__ uint32_t sRow[38 * 64];
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x, frame = blockIdx.y;
+  int tile, frame;
+  xcd_map(P.totalTiles, P.nframes, frame, tile);
   int level = 0;
   for (int l = 1; l < P.nlevels; l++)
     if (tile >= P.geom[l].tileBase) level = l;
@@ -771,8 +788,9 @@ struct KpOut { float x, y, size, angle, response; int32_t octave, class_id; };
 
 __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int frame = blockIdx.y;
+  int frame, blk;
+  xcd_map((P.totalKp + 3) / 4, P.nframes, frame, blk);
+  const int j = blk * 4 + (threadIdx.x >> 6);
   if (j >= P.totalKp) return;
   int level = 0;
   for (int l = 1; l < P.nlevels; l++)

@@ -416,16 +416,16 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
     const size_t lds = align_up((size_t)G.w * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;
     if (lds > 48 * 1024) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_resize, dim3((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, nframes), dim3(256), lds, s, P, l, rowBytes);
+    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
   }
   if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
-  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells, nframes), dim3(256), 0, s, P);
+  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
   hipLaunchKernelGGL(k_octree<256>, dim3(h->nlevels, nframes), dim3(256), 72 * (size_t)h->octCap + 128, s, P, (uint32_t *)h->d_cellOff.p);
   if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
-  hipLaunchKernelGGL(k_blur, dim3(h->totalTiles, nframes), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[4], s));
-  hipLaunchKernelGGL(k_describe, dim3((h->totalKp + 3) / 4, nframes), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(k_describe, dim3(((h->totalKp + 3) / 4) * nframes), dim3(256), 0, s, P);
   hipLaunchKernelGGL(k_counts, dim3((nframes + 63) / 64), dim3(64), 0, s, P);
   if (prof) { XCHECK(h, hipEventRecord(h->ev[5], s)); h->stage_valid = true; }
   XCHECK(h, hipGetLastError());
@@ -464,6 +464,18 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
     XCHECK(h, hipMemcpy(descriptors, h->d_odesc.p, 32 * (size_t)counts[0], hipMemcpyDeviceToHost));
   }
   return counts[1];
+}
+
+// Known-traffic kernel for calibrating the HBM PMC counters in this library's access pattern (4 B per lane, the
+// width k_fast / k_blur / k_resize load with): reads nbytes, writes nbytes.  See tools/collect_traffic.py.
+__global__ __launch_bounds__(256) void k_calib_copy_u32(const uint32_t *src, uint32_t *dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *stream) {
+  if (!d_src || !d_dst || nbytes < 4) return ORBX_E_ARG;
+  hipLaunchKernelGGL(k_calib_copy_u32, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_src, (uint32_t *)d_dst, nbytes / 4);
+  return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
 }
 
 int orbx_level_info(const orbx_t *h, int level, int *rows, int *cols) {
@@ -548,7 +560,7 @@ struct orbm_handle {
   hipStream_t stream = nullptr;
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   bool profiling = false;
-  hipEvent_t ev[2] = {};
+  hipEvent_t ev[3] = {};
   bool ev_ok = false, ms_valid = false;
   std::string err;
 };
@@ -581,7 +593,7 @@ void orbm_destroy(orbm_t *m) {
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
                     &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk};
   for (DevBuf *b : bufs) b->release();
-  if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); }
+  if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); (void)hipEventDestroy(m->ev[2]); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -593,16 +605,24 @@ void orbm_set_profiling(orbm_t *m, int enable) {
   m->profiling = enable != 0;
   if (m->profiling && !m->ev_ok) {
     (void)hipSetDevice(m->device);
-    m->ev_ok = hipEventCreate(&m->ev[0]) == hipSuccess && hipEventCreate(&m->ev[1]) == hipSuccess;
+    m->ev_ok = hipEventCreate(&m->ev[0]) == hipSuccess && hipEventCreate(&m->ev[1]) == hipSuccess && hipEventCreate(&m->ev[2]) == hipSuccess;
   }
 }
 
 float orbm_get_last_ms(orbm_t *m) {
   if (!m || !m->profiling || !m->ev_ok || !m->ms_valid) return -1.f;
   float t = -1.f;
-  if (hipEventSynchronize(m->ev[1]) != hipSuccess) return -1.f;
-  if (hipEventElapsedTime(&t, m->ev[0], m->ev[1]) != hipSuccess) return -1.f;
+  if (hipEventSynchronize(m->ev[2]) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&t, m->ev[0], m->ev[2]) != hipSuccess) return -1.f;
   return t;
+}
+
+int orbm_get_stage_ms(orbm_t *m, float *ms, int cap) {
+  if (!m || !ms || cap < 2 || !m->profiling || !m->ev_ok || !m->ms_valid) return 0;
+  if (hipEventSynchronize(m->ev[2]) != hipSuccess) return 0;
+  if (hipEventElapsedTime(&ms[0], m->ev[0], m->ev[1]) != hipSuccess) return 0;
+  if (hipEventElapsedTime(&ms[1], m->ev[1], m->ev[2]) != hipSuccess) return 0;
+  return 2;
 }
 
 // ORBmatcher.cc:2463-2483 (the bit trick there computes exactly popcount)
@@ -700,12 +720,13 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
       MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
     hipLaunchKernelGGL(k_match_scan<KT>, sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                           \
+    if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
     hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);     \
   } while (0)
   if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
   else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
 #undef LAUNCH_MATCH
-  if (prof) { MCHECK(m, hipEventRecord(m->ev[1], s)); m->ms_valid = true; }
+  if (prof) { MCHECK(m, hipEventRecord(m->ev[2], s)); m->ms_valid = true; }
   MCHECK(m, hipGetLastError());
   return 0;
 }

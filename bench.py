@@ -196,7 +196,7 @@ def main():
         torch.cuda.synchronize()
         st = ex.stage_ms()
         if not args.no_match:
-            st["search"] = mt.last_ms()
+            st.update(mt.stage_ms())
         for k, v in st.items():
             acc[k] = acc.get(k, 0.0) + v / nprof
     ex.set_profiling(False)
@@ -206,16 +206,29 @@ def main():
     cnt = d_cnt[1:].cpu().numpy()
     n_kp = float(cnt[:, 0].mean())
     nm = d_nm.cpu().numpy()
+    # ---- roofline of the dominant KERNEL (per launch).  Stage -> kernel: "pyramid" is nlevels-1 launches of k_resize.
     stage_bytes = algorithmic_bytes(level_shapes, n_kp)
-    stage_bytes["search"] = (n_kp + n_kp) * 32 + n_kp * 12           # SURVEY.md 8d, match
-    dom = max(acc, key=acc.get)
-    if dom == "pyramid":
-        # 7 k_resize launches are timed together; per-launch average over the 7 launches
-        ach = stage_bytes["pyramid"] * B / (acc[dom] * 1e-3) / 1e9
-    else:
-        ach = stage_bytes.get(dom, 0) * B / (acc[dom] * 1e-3) / 1e9
+    stage_bytes["match_scan"] = (n_kp + n_kp) * 32 + n_kp * 12        # SURVEY.md 8d, match: descriptors in, indices out
+    stage_bytes["match_resolve"] = n_kp * (8 * 4 + 12)                # top-8 keys in, (index, distance, count) out
+    kernels = {"pyramid": ("k_resize", CFG["nlevels"] - 1), "fast": ("k_fast", 1), "octree": ("k_octree", 1), "blur": ("k_blur", 1),
+               "describe": ("k_describe", 1), "match_scan": ("k_match_scan", 1), "match_resolve": ("k_match_resolve", 1)}
+    per_launch = {k: acc[k] / kernels[k][1] for k in acc}
+    dom = max(per_launch, key=per_launch.get)
+    kname, nl = kernels[dom]
+    launch_bytes = stage_bytes.get(dom, 0) * B / nl
+    ach = launch_bytes / (per_launch[dom] * 1e-3) / 1e9
     fps = world * B * args.steps / dt
-    total_bytes = sum(stage_bytes[k] for k in ("pyramid", "fast", "blur", "describe")) + (0 if args.no_match else stage_bytes["search"])
+    total_bytes = sum(stage_bytes[k] for k in ("pyramid", "fast", "blur", "describe")) + (0 if args.no_match else stage_bytes["match_scan"])
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")              # measured separately with rocprofv3 --pmc (tools/collect_traffic.py)
+    if os.path.exists(tf) and B == 256:
+        try:
+            tj = json.load(open(tf))
+            hit = [v for k, v in tj.items() if k.startswith(kname)]
+            if hit:
+                traffic = round(hit[0]["hbm_B"])
+        except Exception:
+            traffic = None
 
     if rank == 0:
         out = {
@@ -227,8 +240,9 @@ def main():
                        "image": "%dx%d" % (W, H), "nfeatures": 1000, "nlevels": 8, "frames_per_step_per_gpu": B, "streams": len(pipes),
                        "mean_keypoints_per_frame": round(n_kp, 1), "mean_matches_per_frame": round(float(nm.mean()), 1),
                        "sharding": "frames round-robin, one process per GPU, no collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(launch_bytes), "avg_launch_ms": round(per_launch[dom], 4),
                          "stage_ms_per_step": {k: round(v, 4) for k, v in acc.items()},
                          "pipeline_algorithmic_GBps": round(fps / world * total_bytes / 1e9, 2)},
         }

@@ -101,6 +101,11 @@ int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, i
 void orbx_set_profiling(orbx_t *h, int enable);
 int orbx_get_stage_ms(orbx_t *h, float *ms, int cap);
 
+/* Measurement aid: copies nbytes device->device with 4-byte-per-lane accesses (known HBM traffic: nbytes read +
+ * nbytes written) so that the rocprofv3 FETCH_SIZE/WRITE_SIZE counters can be calibrated in this library's access
+ * pattern (tools/collect_traffic.py). */
+int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *stream);
+
 /* Device replica of the libm cosf/sinf the reference calls at ORBextractor.cc:111, exposed for the exhaustive
  * host-side check in tests (host evaluation of the same source the kernel compiles). */
 float orbx_ref_cosf(float x);
@@ -201,6 +206,8 @@ void orbm_project(int cam_type, const float *params, float X, float Y, float Z, 
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */
 void orbm_set_profiling(orbm_t *m, int enable);
 float orbm_get_last_ms(orbm_t *m);
+/* Per-kernel split of the same: ms[0] = k_match_scan, ms[1] = k_match_resolve.  Returns 2, or 0 if unavailable. */
+int orbm_get_stage_ms(orbm_t *m, float *ms, int cap);
 
 #ifdef __cplusplus
 }
