@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[60 * 60];
-  __shared__ uint32_t sKept[1024], sOut[1024];
+  __shared__ uint32_t sKept[1024];
   __shared__ uint32_t sCount, sNList, sNKept, sNOut;
   const int tid = threadIdx.x, lane = tid & 63;
   int cellId, frame;
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   }
   __syncthreads();
   const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
+  uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (4752 B >= 1024 entries): keeps LDS at ~20 KB = 8 workgroups per CU
   const int nkept = (int)sNKept;
   for (int e = tid; e < nkept; e += 256) {
     const uint32_t v = sKept[e];
