@@ -44,7 +44,7 @@ struct LevelGeom {
 };
 
 struct FrameParams {
-  const LevelGeom *geom;  // device, [nlevels]
+  LevelGeom geom[ORB_MAXL];  // by value: lives in the kernarg segment, so every geometry access is a scalar load
   int nlevels;
   int nframes;
   int iniTh, minTh;

@@ -66,7 +66,7 @@ struct orbx_handle {
   int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
-  DevBuf d_geom, d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_xtab,
+  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_xtab,
       d_ytab, d_disc;
   DevBuf d_img, d_okps, d_odesc, d_ocounts;  // staging for the host entry point
   hipStream_t stream = nullptr;
@@ -173,7 +173,7 @@ void orbx_destroy(orbx_t *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf *bufs[] = {&h->d_geom, &h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
+  DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
                     &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
   if (h->ev_ok)
@@ -314,8 +314,6 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   h->octCap = octCap;
   h->maxKeypoints = kps;
   const size_t B = (size_t)max_batch;
-  XCHECK(h, h->d_geom.reserve(sizeof(LevelGeom) * nl));
-  XCHECK(h, hipMemcpy(h->d_geom.p, g.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
   XCHECK(h, h->d_pyr.reserve(h->pyr_fs * B));
   XCHECK(h, h->d_blur.reserve(h->blur_fs * B));
   XCHECK(h, h->d_cellCnt.reserve(sizeof(uint32_t) * h->cell_fs * B));
@@ -377,7 +375,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   hipStream_t s = (hipStream_t)stream_;  // verbatim: NULL is the device's default stream
   FrameParams P;
   memset(&P, 0, sizeof(P));
-  P.geom = (const LevelGeom *)h->d_geom.p;
+  for (int l = 0; l < h->nlevels; l++) P.geom[l] = h->geom[l];
   P.nlevels = h->nlevels;
   P.nframes = nframes;
   P.iniTh = h->iniThFAST;
