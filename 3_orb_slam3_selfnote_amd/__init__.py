@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -41,6 +41,12 @@ ABI_SYMBOLS = [
 class FrameStruct(C.Structure):  # orbm_frame_t
     _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+class KeyFrameStruct(C.Structure):  # orbm_keyframe_t
+    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
+                ("has_mappoint", C.c_void_p), ("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
+                ("node_idx", C.c_void_p), ("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p), ("nlevels", C.c_int32)]
 
 
 class QueryStruct(C.Structure):  # orbm_queries_t
@@ -107,6 +113,7 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, f32, i32, i32,
                                                          vp, vp, vp, vp, vp, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     L.orbm_search_by_projection_last_frame.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32,
                                                        i32, i32, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, i32, vp, vp, vp]
@@ -293,6 +300,32 @@ class FrameView:
                            C.c_float(self.bounds[1]), C.c_float(self.bounds[2]), C.c_float(self.bounds[3]))
 
 
+class KeyFrameView:
+    """The slice of ORB_SLAM3::KeyFrame that SearchForTriangulation reads: mvKeysUn, mDescriptors, mvuRight, the map-point
+    occupancy, mFeatVec (as {node id: [indices]}), mvScaleFactors, mvLevelSigma2."""
+
+    def __init__(self, keys_un, descriptors, feat_vec, scale_factors, level_sigma2, u_right=None, has_mappoint=None):
+        self.keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+        self.descriptors = np.ascontiguousarray(descriptors, dtype=np.uint8)
+        self.N = len(self.keys_un)
+        self.u_right = np.full(self.N, -1, np.float32) if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+        self.has_mappoint = np.zeros(self.N, np.uint8) if has_mappoint is None else np.ascontiguousarray(has_mappoint, dtype=np.uint8)
+        ids = sorted(feat_vec.keys())                      # std::map iteration order
+        self.node_id = np.array(ids, dtype=np.uint32)
+        self.node_start = np.zeros(len(ids) + 1, dtype=np.int32)
+        idx = []
+        for k, nid in enumerate(ids):
+            idx.extend(int(i) for i in feat_vec[nid])
+            self.node_start[k + 1] = len(idx)
+        self.node_idx = np.array(idx, dtype=np.int32) if idx else np.zeros(1, np.int32)
+        self.sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        self.sigma2 = np.ascontiguousarray(level_sigma2, dtype=np.float32)
+
+    def struct(self):
+        return KeyFrameStruct(self.N, _p(self.keys_un), _p(self.descriptors), _p(self.u_right), _p(self.has_mappoint), len(self.node_id),
+                              _p(self.node_id), _p(self.node_start), _p(self.node_idx), _p(self.sf), _p(self.sigma2), len(self.sf))
+
+
 class ORBmatcher:
     """ORB_SLAM3::ORBmatcher (ORBmatcher.h:35-108) -- the projection-search members, on one MI355X."""
     TH_LOW = 50
@@ -400,6 +433,22 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_search_by_projection_last_frame rc=%d" % rc)
         return rc
+
+    def SearchForTriangulation(self, KF1, KF2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) -- ORBmatcher.cc:981-1222.
+        Returns (nmatches, vMatchedPairs as an int array [k, 2])."""
+        a = lambda x: np.ascontiguousarray(x, dtype=np.float32)
+        R1w, t1w, R2w, t2w, Cw1, cam1, cam2 = a(R1w), a(t1w), a(R2w), a(t2w), a(Cw1), a(cam1), a(cam2)
+        m12 = np.full(max(KF1.N, 1), -1, dtype=np.int32)
+        s1, s2 = KF1.struct(), KF2.struct()
+        rc = self.L.orbm_search_for_triangulation(self.m, C.byref(s1), C.byref(s2), _p(R1w), _p(t1w), _p(R2w), _p(t2w), _p(Cw1), _p(cam1),
+                                                  _p(cam2), int(bool(bOnlyStereo)), int(bool(bCoarse)), int(self.mbCheckOrientation), _p(m12))
+        self._check(rc, "orbm_search_for_triangulation")
+        if rc < 0:
+            raise OrbError("orbm_search_for_triangulation rc=%d" % rc)
+        m12 = m12[:KF1.N]
+        i1 = np.nonzero(m12 >= 0)[0]
+        return rc, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
 
     def hamming_matrix(self, q, c):
         q = np.ascontiguousarray(q, dtype=np.uint8)

@@ -424,6 +424,73 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   }
 }
 
+// SearchForTriangulation inner loops (ORBmatcher.cc:1080-1153): one wavefront per unmatched keypoint of KF1, lanes over
+// the keypoints of KF2 in the same vocabulary node.  The reference keeps a running best with `dist>bestDist -> skip`
+// and updates it only when the geometric gates pass, i.e. the result is the LAST minimum among the gated candidates
+// with dist <= TH_LOW: key = dist<<16 | (0xffff - position), wave minimum.
+struct TriItem { int32_t idx1, start2, len2; };
+struct TriParams {
+  const float *kp1, *kp2;                 // keypoint AoS (7 floats each)
+  const uint32_t *desc1, *desc2;
+  const float *ur1, *ur2;
+  const uint8_t *hasmp2;
+  const int32_t *node_idx2;
+  const TriItem *items; int nitems;
+  float sf2[ORBX_MAX_LEVELS], sigma2_2[ORBX_MAX_LEVELS];
+  float F12[9];
+  float epx, epy;
+  int bOnlyStereo, bCoarse;
+  int32_t *matches12;
+};
+
+__global__ __launch_bounds__(256) void k_triangulation_match(TriParams T) {
+  const int lane = threadIdx.x & 63;
+  const int it = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= T.nitems) return;
+  const TriItem item = T.items[it];
+  const int idx1 = item.idx1;
+  uint32_t d1[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) d1[w] = T.desc1[(size_t)idx1 * 8 + w];
+  const float x1 = T.kp1[(size_t)idx1 * 7], y1 = T.kp1[(size_t)idx1 * 7 + 1];
+  const bool bStereo1 = T.ur1[idx1] >= 0.f;
+  // epipolar line of kp1 in image 2, Pinhole.cpp:150-153
+  const float a = x1 * T.F12[0] + y1 * T.F12[3] + T.F12[6];
+  const float b = x1 * T.F12[1] + y1 * T.F12[4] + T.F12[7];
+  const float c = x1 * T.F12[2] + y1 * T.F12[5] + T.F12[8];
+  const float den = a * a + b * b;
+  uint32_t best = 0xffffffffu;
+  for (int j = lane; j < item.len2; j += 64) {
+    const int idx2 = T.node_idx2[item.start2 + j];
+    if (T.hasmp2[idx2]) continue;                                   // :1083 (vbMatched2 is never set)
+    const bool bStereo2 = T.ur2[idx2] >= 0.f;
+    if (T.bOnlyStereo && !bStereo2) continue;                       // :1088-1090
+    int dist = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) dist += __popc(d1[w] ^ T.desc2[(size_t)idx2 * 8 + w]);
+    if (dist > ORBM_TH_LOW) continue;                               // :1096
+    const float x2 = T.kp2[(size_t)idx2 * 7], y2 = T.kp2[(size_t)idx2 * 7 + 1];
+    const int oct2 = __float_as_int(T.kp2[(size_t)idx2 * 7 + 5]);
+    if (!bStereo1 && !bStereo2) {                                   // :1105-1113
+      const float distex = T.epx - x2, distey = T.epy - y2;
+      if (distex * distex + distey * distey < 100 * T.sf2[oct2]) continue;
+    }
+    bool ok = T.bCoarse != 0;
+    if (!ok && den != 0) {                                          // Pinhole.cpp:155-164
+      const float num = a * x2 + b * y2 + c;
+      const float dsqr = num * num / den;
+      ok = (double)dsqr < 3.84 * (double)T.sigma2_2[oct2];
+    }
+    if (ok) {
+      const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)(0xffff - j);
+      best = key < best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
+  if (lane == 0) T.matches12[idx1] = best != 0xffffffffu ? T.node_idx2[item.start2 + (0xffff - (int)(best & 0xffff))] : -1;
+}
+
 // K8 brute force: dist[i][j] = popcount(q_i ^ c_j).  Candidates staged through LDS in 256-descriptor (8 KB) chunks.
 __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t *q, int nq, const uint32_t *c, int nc, uint16_t *dist) {
   __shared__ uint32_t sC[256 * 9];  // +1 word pad per descriptor: conflict-free column reads

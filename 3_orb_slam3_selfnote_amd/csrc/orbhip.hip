@@ -866,6 +866,139 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
   return nmatches;
 }
 
+// ---- SearchForTriangulation (ORBmatcher.cc:981-1222), Pinhole / Pinhole, no second camera --------------------------------
+namespace {
+// cv::Mat algebra of ORBmatcher.cc:988-1010 and Pinhole.cpp:143-148 restated ([OPENCV-UNVERIFIED]):
+// products without flags take cv::gemm's small-matrix float path, transposed / scaled operands the generic path with
+// double accumulation, cv::invert(3x3 CV_32F) evaluates the cofactor formula in double.
+void mul33(const float *A, const float *B, float *D) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) D[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+void inv33(const float *S, float *D) {
+  const double s00 = S[0], s01 = S[1], s02 = S[2], s10 = S[3], s11 = S[4], s12 = S[5], s20 = S[6], s21 = S[7], s22 = S[8];
+  double det = s00 * (s11 * s22 - s12 * s21) - s01 * (s10 * s22 - s12 * s20) + s02 * (s10 * s21 - s11 * s20);
+  if (det == 0.) { for (int i = 0; i < 9; i++) D[i] = 0.f; return; }
+  det = 1. / det;
+  D[0] = (float)((s11 * s22 - s12 * s21) * det); D[1] = (float)((s02 * s21 - s01 * s22) * det); D[2] = (float)((s01 * s12 - s02 * s11) * det);
+  D[3] = (float)((s12 * s20 - s10 * s22) * det); D[4] = (float)((s00 * s22 - s02 * s20) * det); D[5] = (float)((s02 * s10 - s00 * s12) * det);
+  D[6] = (float)((s10 * s21 - s11 * s20) * det); D[7] = (float)((s01 * s20 - s00 * s21) * det); D[8] = (float)((s00 * s11 - s01 * s10) * det);
+}
+}  // namespace
+
+int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, const float *R1w, const float *t1w,
+                                  const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
+                                  int bOnlyStereo, int bCoarse, int checkOri, int32_t *matches12) {
+  if (!m || !k1 || !k2 || !R1w || !t1w || !R2w || !t2w || !Cw1 || !cam1 || !cam2 || !matches12) return ORBX_E_ARG;
+  if (k1->n < 0 || k2->n < 0 || k2->nlevels < 1 || k2->nlevels > ORBX_MAX_LEVELS) return ORBX_E_ARG;
+  for (int i = 0; i < k1->n; i++) matches12[i] = -1;
+  if (k1->n == 0 || k2->n == 0 || k1->n_nodes == 0 || k2->n_nodes == 0) return 0;
+  if (!k1->u_right || !k2->u_right || !k1->has_mappoint || !k2->has_mappoint) return ORBX_E_ARG;
+  TriParams T;
+  memset(&T, 0, sizeof(T));
+  // epipole in image 2: C2 = R2w*Cw+t2w, ep = pCamera2->project(C2), :988-994
+  float C2[3];
+  for (int i = 0; i < 3; i++) {
+    const float t0 = R2w[3 * i] * Cw1[0] + R2w[3 * i + 1] * Cw1[1] + R2w[3 * i + 2] * Cw1[2];
+    C2[i] = (float)((double)t0 + (double)t2w[i]);
+  }
+  orbm_project(0, cam2, C2[0], C2[1], C2[2], &T.epx, &T.epy);
+  // R12 = R1w*R2w.t(); t12 = -R1w*R2w.t()*t2w+t1w, :1008-1010
+  float R12[9], nR[9], t12[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += (double)R1w[3 * i + k] * (double)R2w[3 * j + k];
+      R12[3 * i + j] = (float)acc;
+      nR[3 * i + j] = (float)(-acc);
+    }
+  for (int i = 0; i < 3; i++) {
+    const float t0 = nR[3 * i] * t2w[0] + nR[3 * i + 1] * t2w[1] + nR[3 * i + 2] * t2w[2];
+    t12[i] = (float)((double)t0 + (double)t1w[i]);
+  }
+  {  // F12 = K1.t().inv()*t12x*R12*K2.inv(), Pinhole.cpp:145-148
+    const float tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+    const float K1t[9] = {cam1[0], 0.f, 0.f, 0.f, cam1[1], 0.f, cam1[2], cam1[3], 1.f};
+    const float K2[9] = {cam2[0], 0.f, cam2[2], 0.f, cam2[1], cam2[3], 0.f, 0.f, 1.f};
+    float K1ti[9], K2i[9], A[9], B[9];
+    inv33(K1t, K1ti);
+    inv33(K2, K2i);
+    mul33(K1ti, tx, A);
+    mul33(A, R12, B);
+    mul33(B, K2i, T.F12);
+  }
+  // merge-walk of the two feature vectors (:1036-1188): one work item per unmatched keypoint of KF1 in a shared node
+  std::vector<TriItem> items;
+  int f1 = 0, f2 = 0;
+  while (f1 < k1->n_nodes && f2 < k2->n_nodes) {
+    if (k1->node_id[f1] == k2->node_id[f2]) {
+      const int s2 = k2->node_start[f2], l2 = k2->node_start[f2 + 1] - s2;
+      if (l2 > 0xffff) { m->err = "vocabulary node with more than 65535 keypoints"; return ORBX_E_ARG; }
+      for (int i1 = k1->node_start[f1]; i1 < k1->node_start[f1 + 1]; i1++) {
+        const int idx1 = k1->node_idx[i1];
+        if (idx1 < 0 || idx1 >= k1->n) return ORBX_E_ARG;
+        if (k1->has_mappoint[idx1]) continue;                          // :1050-1055
+        if (bOnlyStereo && !(k1->u_right[idx1] >= 0)) continue;        // :1057-1061
+        if (l2 > 0) items.push_back(TriItem{idx1, s2, l2});
+      }
+      f1++; f2++;
+    } else if (k1->node_id[f1] < k2->node_id[f2]) {
+      while (f1 < k1->n_nodes && k1->node_id[f1] < k2->node_id[f2]) f1++;
+    } else {
+      while (f2 < k2->n_nodes && k2->node_id[f2] < k1->node_id[f1]) f2++;
+    }
+  }
+  int nmatches = 0;
+  if (!items.empty()) {
+    MCHECK(m, hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t nidx2 = (size_t)k2->node_start[k2->n_nodes];
+    DevBuf *B[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qfl, &m->d_qi[0], &m->d_qi[1], &m->d_moq};
+    const void *src[] = {k1->keys_un, k1->descriptors, k1->u_right, k2->descriptors, k2->keys_un, k2->u_right, k2->has_mappoint, k2->node_idx, items.data(), nullptr};
+    const size_t bytes[] = {sizeof(orbx_keypoint_t) * (size_t)k1->n, 32 * (size_t)k1->n, sizeof(float) * (size_t)k1->n, 32 * (size_t)k2->n,
+                            sizeof(orbx_keypoint_t) * (size_t)k2->n, sizeof(float) * (size_t)k2->n, (size_t)k2->n, sizeof(int32_t) * nidx2,
+                            sizeof(TriItem) * items.size(), sizeof(int32_t) * (size_t)k1->n};
+    for (int i = 0; i < 10; i++) {
+      MCHECK(m, B[i]->reserve(std::max<size_t>(bytes[i], 4)));
+      if (src[i]) MCHECK(m, hipMemcpyAsync(B[i]->p, src[i], bytes[i], hipMemcpyHostToDevice, s));
+    }
+    MCHECK(m, hipMemsetAsync(m->d_moq.p, 0xff, bytes[9], s));
+    T.kp1 = (const float *)m->d_kp.p; T.desc1 = (const uint32_t *)m->d_desc.p; T.ur1 = (const float *)m->d_ur.p;
+    T.desc2 = (const uint32_t *)m->d_qdesc.p; T.kp2 = (const float *)m->d_qf[0].p; T.ur2 = (const float *)m->d_qf[1].p;
+    T.hasmp2 = (const uint8_t *)m->d_qfl.p; T.node_idx2 = (const int32_t *)m->d_qi[0].p;
+    T.items = (const TriItem *)m->d_qi[1].p; T.nitems = (int)items.size();
+    for (int l = 0; l < k2->nlevels; l++) { T.sf2[l] = k2->scale_factors[l]; T.sigma2_2[l] = k2->level_sigma2[l]; }
+    T.bOnlyStereo = bOnlyStereo; T.bCoarse = bCoarse;
+    T.matches12 = (int32_t *)m->d_moq.p;
+    hipLaunchKernelGGL(k_triangulation_match, dim3((T.nitems + 3) / 4), dim3(256), 0, s, T);
+    MCHECK(m, hipGetLastError());
+    MCHECK(m, hipMemcpyAsync(matches12, m->d_moq.p, bytes[9], hipMemcpyDeviceToHost, s));
+    MCHECK(m, hipStreamSynchronize(s));
+    for (int i = 0; i < k1->n; i++) nmatches += matches12[i] >= 0;
+  }
+  if (checkOri && nmatches > 0) {  // :1162-1172, :1191-1207
+    std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    // the reference fills the histogram in merge-walk order; only the bin sizes matter afterwards
+    for (int i = 0; i < k1->n; i++) {
+      if (matches12[i] < 0) continue;
+      float rot = k1->keys_un[i].angle - k2->keys_un[matches12[i]].angle;
+      if ((double)rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == ORBM_HISTO_LENGTH) bin = 0;
+      if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(i);
+    }
+    int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+    orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

@@ -192,6 +192,38 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
                                          const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
                                          float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* The slice of KeyFrame that SearchForTriangulation reads (host pointers).  feature vector = DBoW2::FeatureVector
+ * (std::map<NodeId, std::vector<unsigned>>, FeatureVector.h:24-25) flattened in key order: node_id[k] ascending,
+ * members of node k = node_idx[node_start[k] .. node_start[k+1]). */
+typedef struct {
+  int32_t n;
+  const orbx_keypoint_t *keys_un;  /* mvKeysUn.data() */
+  const uint8_t *descriptors;      /* mDescriptors, n x 32 */
+  const float *u_right;            /* mvuRight (negative = monocular keypoint) */
+  const uint8_t *has_mappoint;     /* GetMapPoint(i) != NULL */
+  int32_t n_nodes;
+  const uint32_t *node_id;
+  const int32_t *node_start;       /* n_nodes + 1 */
+  const int32_t *node_idx;
+  const float *scale_factors;      /* mvScaleFactors */
+  const float *level_sigma2;       /* mvLevelSigma2 */
+  int32_t nlevels;
+} orbm_keyframe_t;
+
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>>&,
+ *                                        const bool bOnlyStereo, const bool bCoarse)        (ORBmatcher.cc:981-1222)
+ * for two Pinhole keyframes without a second camera (mpCamera2 == NULL; F12 is unused by the reference as well).
+ * R?w / t?w = GetRotation() / GetTranslation() (row-major 3x3 / 3), Cw1 = pKF1->GetCameraCenter(),
+ * cam? = mvParameters {fx, fy, cx, cy}.  The merge-walk over the two feature vectors and the per-pair fundamental
+ * matrix (Pinhole.cpp:143-148, identical for every candidate pair, so formed once) run on the host; the per-node
+ * all-pairs Hamming scan with the epipole / epipolar gates runs on the device.  matches12[kf1->n] (out) =
+ * vMatches12; the reference's vMatchedPairs is {(i, matches12[i]) : matches12[i] >= 0} in ascending i.
+ * Returns nmatches. */
+int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, const float *R1w,
+                                  const float *t1w, const float *R2w, const float *t2w, const float *Cw1,
+                                  const float *cam1, const float *cam2, int bOnlyStereo, int bCoarse, int checkOri,
+                                  int32_t *matches12);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

@@ -270,6 +270,50 @@ class OracleFrame:
                                                   _p(self.slot), _p(self.slot_obs))
 
 
+class KeyFrame(C.Structure):
+    _fields_ = [("N", C.c_int), ("kx", C.c_void_p), ("ky", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("desc", C.c_void_p),
+                ("uRight", C.c_void_p), ("has_mp", C.c_void_p), ("n_nodes", C.c_int), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
+                ("node_idx", C.c_void_p), ("scaleFactors", C.c_void_p), ("levelSigma2", C.c_void_p)]
+
+
+class OracleKeyFrame:
+    """The slice of KeyFrame read by SearchForTriangulation (ORBmatcher.cc:981-1222)."""
+
+    def __init__(self, keys_un, desc, feat_vec, scale_factors, level_sigma2, u_right=None, has_mp=None):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        self.N = len(keys_un)
+        self.kx, self.ky = a(keys_un["x"], np.float32), a(keys_un["y"], np.float32)
+        self.octave, self.angle = a(keys_un["octave"], np.int32), a(keys_un["angle"], np.float32)
+        self.desc = a(desc, np.uint8)
+        self.u_right = np.full(self.N, -1, np.float32) if u_right is None else a(u_right, np.float32)
+        self.has_mp = np.zeros(self.N, np.uint8) if has_mp is None else a(has_mp, np.uint8)
+        ids = sorted(feat_vec.keys())
+        self.node_id = np.array(ids, dtype=np.uint32)
+        self.node_start = np.zeros(len(ids) + 1, dtype=np.int32)
+        idx = []
+        for k, nid in enumerate(ids):
+            idx.extend(int(i) for i in feat_vec[nid])
+            self.node_start[k + 1] = len(idx)
+        self.node_idx = np.array(idx, dtype=np.int32) if idx else np.zeros(1, np.int32)
+        self.sf, self.sigma2 = a(scale_factors, np.float32), a(level_sigma2, np.float32)
+        self.k = KeyFrame(self.N, *[v.ctypes.data for v in (self.kx, self.ky, self.octave, self.angle, self.desc, self.u_right, self.has_mp)],
+                          len(ids), self.node_id.ctypes.data, self.node_start.ctypes.data, self.node_idx.ctypes.data, self.sf.ctypes.data,
+                          self.sigma2.ctypes.data)
+
+
+def search_for_triangulation(K1, K2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, only_stereo=False, coarse=False, check_ori=False):
+    a = lambda x: np.ascontiguousarray(x, dtype=np.float32)
+    R1w, t1w, R2w, t2w, Cw1, cam1, cam2 = a(R1w), a(t1w), a(R2w), a(t2w), a(Cw1), a(cam1), a(cam2)
+    m12 = np.full(max(K1.N, 1), -1, dtype=np.int32)
+    L = lib()
+    L.orc_search_for_triangulation.argtypes = [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p]
+    n = L.orc_search_for_triangulation(C.byref(K1.k), C.byref(K2.k), _p(R1w), _p(t1w), _p(R2w), _p(t2w), _p(Cw1), _p(cam1), _p(cam2),
+                                       int(only_stereo), int(coarse), int(check_ori), _p(m12))
+    m12 = m12[:K1.N]
+    i1 = np.nonzero(m12 >= 0)[0]
+    return n, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
+
+
 def project(cam_type, params, X, Y, Z):
     params = np.ascontiguousarray(params, dtype=np.float32)
     u, v = C.c_float(), C.c_float()

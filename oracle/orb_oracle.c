@@ -1064,3 +1064,152 @@ int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp
   free(vIndices2);
   return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* M6, ORBmatcher.cc:981-1222 + Pinhole::epipolarConstrain, Pinhole.cpp:143-165                 */
+/* cv::Mat algebra restated per SURVEY.md A.8 [OPENCV-UNVERIFIED]:                              */
+/*  - 3x3 * 3x3 / 3x3 * 3x1 products without flags: float dot products (a0*b0+a1*b1+a2*b2 in    */
+/*    float), then (float)(t*alpha + c*beta) in double;                                         */
+/*  - products with a transposed operand or a scalar factor go through the generic gemm that    */
+/*    accumulates in double;                                                                    */
+/*  - cv::invert of a 3x3 CV_32F matrix: cofactor formula evaluated in double, stored as float. */
+/* ------------------------------------------------------------------------------------------ */
+static void m33_mul(const float *A, const float *B, float *D) { /* small-matrix float path */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float t = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+      D[i * 3 + j] = (float)((double)t * 1.0);
+    }
+}
+static void m33_inv(const float *S, float *D) {
+#define Sf(y, x) ((double)S[(y) * 3 + (x)])
+  double d = Sf(0, 0) * (Sf(1, 1) * Sf(2, 2) - Sf(1, 2) * Sf(2, 1)) - Sf(0, 1) * (Sf(1, 0) * Sf(2, 2) - Sf(1, 2) * Sf(2, 0)) +
+             Sf(0, 2) * (Sf(1, 0) * Sf(2, 1) - Sf(1, 1) * Sf(2, 0));
+  if (d == 0.) { memset(D, 0, 9 * sizeof(float)); return; }
+  d = 1. / d;
+  double t[9];
+  t[0] = (Sf(1, 1) * Sf(2, 2) - Sf(1, 2) * Sf(2, 1)) * d;
+  t[1] = (Sf(0, 2) * Sf(2, 1) - Sf(0, 1) * Sf(2, 2)) * d;
+  t[2] = (Sf(0, 1) * Sf(1, 2) - Sf(0, 2) * Sf(1, 1)) * d;
+  t[3] = (Sf(1, 2) * Sf(2, 0) - Sf(1, 0) * Sf(2, 2)) * d;
+  t[4] = (Sf(0, 0) * Sf(2, 2) - Sf(0, 2) * Sf(2, 0)) * d;
+  t[5] = (Sf(0, 2) * Sf(1, 0) - Sf(0, 0) * Sf(1, 2)) * d;
+  t[6] = (Sf(1, 0) * Sf(2, 1) - Sf(1, 1) * Sf(2, 0)) * d;
+  t[7] = (Sf(0, 1) * Sf(2, 0) - Sf(0, 0) * Sf(2, 1)) * d;
+  t[8] = (Sf(0, 0) * Sf(1, 1) - Sf(0, 1) * Sf(1, 0)) * d;
+#undef Sf
+  for (int i = 0; i < 9; i++) D[i] = (float)t[i];
+}
+
+void orc_pinhole_F12(const float *R12, const float *t12, const float *cam1, const float *cam2, float *F12) {
+  const float t12x[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};        /* Pinhole.cpp:183-188 */
+  const float K1t[9] = {cam1[0], 0.f, 0.f, 0.f, cam1[1], 0.f, cam1[2], cam1[3], 1.f};        /* K1.t() */
+  const float K2[9] = {cam2[0], 0.f, cam2[2], 0.f, cam2[1], cam2[3], 0.f, 0.f, 1.f};
+  float K1ti[9], K2i[9], A[9], B[9];
+  m33_inv(K1t, K1ti);
+  m33_inv(K2, K2i);
+  m33_mul(K1ti, t12x, A);  /* ((K1.t().inv() * t12x) * R12) * K2.inv() */
+  m33_mul(A, R12, B);
+  m33_mul(B, K2i, F12);
+}
+
+static int epipolar_constrain(const float *F12, float x1, float y1, float x2, float y2, float unc) { /* Pinhole.cpp:150-164 */
+  const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+  const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+  const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+  const float num = a * x2 + b * y2 + c;
+  const float den = a * a + b * b;
+  if (den == 0) return 0;
+  const float dsqr = num * num / den;
+  return (double)dsqr < 3.84 * (double)unc;
+}
+
+int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2, const float *R1w, const float *t1w,
+                                 const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
+                                 int bOnlyStereo, int bCoarse, int checkOri, int32_t *vMatches12) {
+  /* C2 = R2w*Cw+t2w; ep = project(C2), :988-994 */
+  float C2[3];
+  for (int i = 0; i < 3; i++) {
+    float t0 = R2w[i * 3 + 0] * Cw1[0] + R2w[i * 3 + 1] * Cw1[1] + R2w[i * 3 + 2] * Cw1[2];
+    C2[i] = (float)((double)t0 + (double)t2w[i]);
+  }
+  float epx, epy;
+  orc_project(0, cam2, C2[0], C2[1], C2[2], &epx, &epy);
+  /* R12 = R1w*R2w.t(); t12 = -R1w*R2w.t()*t2w+t1w, :1008-1010 */
+  float R12[9], Rm[9], t12[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double sacc = 0;
+      for (int k = 0; k < 3; k++) sacc += (double)R1w[i * 3 + k] * (double)R2w[j * 3 + k];
+      R12[i * 3 + j] = (float)(sacc * 1.0);
+      Rm[i * 3 + j] = (float)(sacc * -1.0);
+    }
+  for (int i = 0; i < 3; i++) {
+    float t0 = Rm[i * 3 + 0] * t2w[0] + Rm[i * 3 + 1] * t2w[1] + Rm[i * 3 + 2] * t2w[2];
+    t12[i] = (float)((double)t0 + (double)t1w[i]);
+  }
+  float F12[9];
+  orc_pinhole_F12(R12, t12, cam1, cam2, F12);
+
+  int nmatches = 0;
+  for (int i = 0; i < k1->N; i++) vMatches12[i] = -1;
+  const int HISTO_LENGTH = 30;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(k1->N + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  int f1 = 0, f2 = 0;
+  while (f1 < k1->n_nodes && f2 < k2->n_nodes) {
+    if (k1->node_id[f1] == k2->node_id[f2]) {
+      for (int i1 = k1->node_start[f1]; i1 < k1->node_start[f1 + 1]; i1++) {
+        const int idx1 = k1->node_idx[i1];
+        if (k1->has_mp[idx1]) continue;
+        const int bStereo1 = k1->uRight[idx1] >= 0;
+        if (bOnlyStereo && !bStereo1) continue;
+        int bestDist = 50 /* TH_LOW */, bestIdx2 = -1;
+        for (int i2 = k2->node_start[f2]; i2 < k2->node_start[f2 + 1]; i2++) {
+          const int idx2 = k2->node_idx[i2];
+          if (k2->has_mp[idx2]) continue;                 /* vbMatched2 is never set (:1027) */
+          const int bStereo2 = k2->uRight[idx2] >= 0;
+          if (bOnlyStereo && !bStereo2) continue;
+          const int dist = orc_descriptor_distance(k1->desc + 32 * (size_t)idx1, k2->desc + 32 * (size_t)idx2);
+          if (dist > 50 || dist > bestDist) continue;
+          if (!bStereo1 && !bStereo2) {
+            const float distex = epx - k2->kx[idx2], distey = epy - k2->ky[idx2];
+            if (distex * distex + distey * distey < 100 * k2->scaleFactors[k2->octave[idx2]]) continue;
+          }
+          if (bCoarse || epipolar_constrain(F12, k1->kx[idx1], k1->ky[idx1], k2->kx[idx2], k2->ky[idx2], k2->levelSigma2[k2->octave[idx2]])) {
+            bestIdx2 = idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (checkOri) {
+            float rot = k1->angle[idx1] - k2->angle[bestIdx2];
+            if ((double)rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin][rotN[bin]++] = idx1;
+          }
+        }
+      }
+      f1++; f2++;
+    } else if (k1->node_id[f1] < k2->node_id[f2]) {
+      while (f1 < k1->n_nodes && k1->node_id[f1] < k2->node_id[f2]) f1++;   /* lower_bound */
+    } else {
+      while (f2 < k2->n_nodes && k2->node_id[f2] < k1->node_id[f1]) f2++;
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < rotN[i]; j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  return nmatches;
+}

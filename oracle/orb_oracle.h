@@ -154,6 +154,31 @@ int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp
                                 const float *Tcw, const float *Tlw, int camType, const float *camParams, float mb, float mbf,
                                 float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* The slice of KeyFrame that SearchForTriangulation reads. */
+typedef struct {
+  int N;
+  const float *kx, *ky;          /* mvKeysUn[i].pt */
+  const int32_t *octave;
+  const float *angle;
+  const uint8_t *desc;
+  const float *uRight;           /* mvuRight (never NULL here; -1 = mono) */
+  const uint8_t *has_mp;         /* GetMapPoint(i) != NULL */
+  int n_nodes;                   /* DBoW2::FeatureVector: nodes ascending by id */
+  const uint32_t *node_id;
+  const int32_t *node_start;     /* n_nodes + 1 */
+  const int32_t *node_idx;
+  const float *scaleFactors, *levelSigma2;
+} orc_keyframe;
+
+/* M6: SearchForTriangulation(KF1, KF2, F12, pairs, bOnlyStereo, bCoarse), ORBmatcher.cc:981-1222, both cameras
+ * Pinhole and no second camera (mpCamera2 == NULL).  R?w row-major 3x3, t?w 3, Cw1 = pKF1->GetCameraCenter().
+ * cam? = [fx, fy, cx, cy].  matches12[N1] out (vMatches12).  Returns nmatches. */
+int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2, const float *R1w, const float *t1w,
+                                 const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
+                                 int bOnlyStereo, int bCoarse, int checkOri, int32_t *matches12);
+/* Pinhole::epipolarConstrain inputs: F12 = K1^-T [t12]x R12 K2^-1 (Pinhole.cpp:143-148), exported for tests. */
+void orc_pinhole_F12(const float *R12, const float *t12, const float *cam1, const float *cam2, float *F12);
+
 /* M7: ComputeThreeMaxima, ORBmatcher.cc:2416-2458, on bin sizes. */
 void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 /* RadiusByViewingCos, ORBmatcher.cc:216-222. */

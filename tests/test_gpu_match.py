@@ -181,3 +181,46 @@ def test_search_by_projection_last_frame_m3(pkg, oracle, synth, matcher, cam, st
         assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
         total += n_ref
     assert total > (100 if cam == 0 else 0)
+
+
+def _bow(desc, nodes=128):
+    """Stand-in for DBoW2's FeatureVector (the ORB vocabulary file is missing from the reference mount,
+    .MISSING_LARGE_BLOBS:5): node id = a hash of descriptor bits, so that similar descriptors mostly share a node."""
+    ids = (desc[:, 0].astype(np.int64) >> 2) * 2 + (desc[:, 7].astype(np.int64) >> 7)
+    fv = {}
+    for i, n in enumerate(ids % nodes):
+        fv.setdefault(int(n) * 7 + 3, []).append(i)      # sparse, unordered ids like real node ids
+    return fv
+
+
+@pytest.mark.parametrize("coarse,only_stereo,check_ori", [(False, False, False), (True, False, True), (False, True, False)])
+def test_search_for_triangulation_m6(pkg, oracle, synth, coarse, only_stereo, check_ori):
+    """ORBmatcher::SearchForTriangulation: vocabulary-node merge walk, all-pairs Hamming inside a node with the running
+    `dist>bestDist` gate (last minimum wins), epipole-distance gate, Pinhole::epipolarConstrain, stereo-only mode."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3300)
+    rng = np.random.default_rng(5)
+    sigma2 = (sf * sf).astype(np.float32)
+    cam = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    z = np.float32(5.0)
+    dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+    R1w, t1w = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    ang = 0.001
+    R2w = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    t2w = np.array([dx * z / cam[0], dy * z / cam[1], 0.02], np.float32)
+    Cw1 = np.zeros(3, np.float32)
+    ur0 = np.where(rng.random(len(k0)) < 0.5, k0["x"] - np.float32(9.0), np.float32(-1)).astype(np.float32)
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - np.float32(9.0), np.float32(-1)).astype(np.float32)
+    mp0 = (rng.random(len(k0)) < 0.2).astype(np.uint8)
+    mp1 = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    fv0, fv1 = _bow(d0), _bow(d1)
+    KF1 = pkg.KeyFrameView(k0, d0, fv0, sf, sigma2, u_right=ur0, has_mappoint=mp0)
+    KF2 = pkg.KeyFrameView(k1, d1, fv1, sf, sigma2, u_right=ur1, has_mappoint=mp1)
+    O1 = oracle.OracleKeyFrame(k0, d0, fv0, sf, sigma2, u_right=ur0, has_mp=mp0)
+    O2 = oracle.OracleKeyFrame(k1, d1, fv1, sf, sigma2, u_right=ur1, has_mp=mp1)
+    m = pkg.ORBmatcher(0.6, check_ori)
+    n_gpu, pairs_gpu = m.SearchForTriangulation(KF1, KF2, R1w, t1w, R2w, t2w, Cw1, cam, cam, bOnlyStereo=only_stereo, bCoarse=coarse)
+    n_ref, pairs_ref = oracle.search_for_triangulation(O1, O2, R1w, t1w, R2w, t2w, Cw1, cam, cam, only_stereo=only_stereo, coarse=coarse,
+                                                       check_ori=check_ori)
+    assert n_gpu == n_ref and n_ref > (20 if only_stereo else 60)
+    assert np.array_equal(pairs_gpu, pairs_ref)
+    m.close()
