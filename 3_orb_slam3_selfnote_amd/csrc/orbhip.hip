@@ -866,6 +866,77 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
   return nmatches;
 }
 
+// Rotation-consistency pruning shared by the projection searches (e.g. ORBmatcher.cc:2177-2185 + :2263-2286).
+static int prune_by_rotation(int nq, const int32_t *moq, const float *query_angle, const orbx_keypoint_t *keys, int32_t *slot,
+                             uint8_t *slot_obs, int nmatches) {
+  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+  const float factor = 1.0f / ORBM_HISTO_LENGTH;
+  for (int i = 0; i < nq; i++) {
+    if (moq[i] < 0) continue;
+    float rot = query_angle[i] - keys[moq[i]].angle;
+    if ((double)rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+    if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(moq[i]);
+  }
+  int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+  orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (int idx : rotHist[i]) { slot[idx] = -1; slot_obs[idx] = 0; nmatches--; }
+  }
+  return nmatches;
+}
+
+int orbm_search_by_projection_keyframe(orbm_t *m, const orbm_frame_t *cur, const float *sf, int nlevels, float logScaleFactor, int nKF,
+                                       const uint8_t *valid, const float *Xw, const uint8_t *mpdesc, const float *kf_angle,
+                                       const float *max_dist, const float *min_dist, const float *Tcw, int cam_type,
+                                       const float *cam_params, float th, int ORBdist, int checkOri, int32_t *slot, uint8_t *slot_obs) {
+  if (!m || !cur || !sf || nlevels < 1 || nKF < 0 || !Tcw || !cam_params || !slot || !slot_obs) return ORBX_E_ARG;
+  if (nKF > 0 && (!valid || !Xw || !mpdesc || !kf_angle || !max_dist || !min_dist)) return ORBX_E_ARG;
+  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+  float Ow[3];  // Ow = -Rcw.t()*tcw, :2297
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)Tcw[4 * k + i] * (double)tcw[k];
+    Ow[i] = (float)(-acc);
+  }
+  std::vector<float> u(nKF, 0.f), v(nKF, 0.f), rad(nKF, 0.f);
+  std::vector<int32_t> minl(nKF, -1), maxl(nKF, -1), moq(nKF, -1);
+  std::vector<uint8_t> flags(nKF, 0);
+  for (int i = 0; i < nKF; i++) {
+    if (!valid[i]) continue;
+    const float *x3Dw = Xw + 3 * i;
+    float x3Dc[3];
+    mat3_mul_add(Tcw, x3Dw, tcw, x3Dc);                                        // :2317
+    float ux, vy;
+    orbm_project(cam_type, cam_params, x3Dc[0], x3Dc[1], x3Dc[2], &ux, &vy);     // :2319
+    if (ux < cur->min_x || ux > cur->max_x) continue;                           // :2321-2324
+    if (vy < cur->min_y || vy > cur->max_y) continue;
+    double n2 = 0;                                                               // cv::norm(x3Dw-Ow), :2327-2328
+    for (int k = 0; k < 3; k++) { const float po = x3Dw[k] - Ow[k]; n2 += (double)po * (double)po; }
+    const float dist3D = (float)sqrt(n2);
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;                 // :2334-2335
+    const float ratio = max_dist[i] / dist3D;                                    // MapPoint::PredictScale, MapPoint.cc:587-602
+    int lvl = (int)ceilf(logf(ratio) / logScaleFactor);
+    lvl = lvl < 0 ? 0 : (lvl >= nlevels ? nlevels - 1 : lvl);
+    u[i] = ux; v[i] = vy;
+    rad[i] = th * sf[lvl];                                                       // :2340
+    minl[i] = lvl - 1; maxl[i] = lvl + 1;                                        // :2342
+    flags[i] = 3;
+  }
+  orbm_queries_t q;
+  q.nq = nKF; q.descriptors = mpdesc; q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = nullptr; q.flags = flags.data();
+  orbm_frame_t f = *cur;
+  f.u_right = nullptr;  // no stereo gate in this overload
+  int nmatches = orbm_search_by_projection(m, &f, &q, 0.f, ORBdist, 0, slot, slot_obs, moq.data(), nullptr);
+  if (nmatches < 0 || !checkOri) return nmatches;
+  return prune_by_rotation(nKF, moq.data(), kf_angle, cur->keys_un, slot, slot_obs, nmatches);
+}
+
 // ---- SearchForTriangulation (ORBmatcher.cc:981-1222), Pinhole / Pinhole, no second camera --------------------------------
 namespace {
 // cv::Mat algebra of ORBmatcher.cc:988-1010 and Pinhole.cpp:143-148 restated ([OPENCV-UNVERIFIED]):

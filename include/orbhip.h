@@ -192,6 +192,19 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
                                          const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
                                          float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
+ *                                    const float th, const int ORBdist)                       (ORBmatcher.cc:2291-2413)
+ * flattened, host pointers.  i in [0, nKF): valid[i] = pMP && !pMP->isBad() && !sAlreadyFound.count(pMP);
+ * Xw = GetWorldPos(); mpdesc = GetDescriptor(); kf_angle[i] = pKF->mvKeysUn[i].angle; max_dist / min_dist =
+ * MapPoint::mfMaxDistance / mfMinDistance (the 1.2 / 0.8 invariance factors of MapPoint.cc:552-563 and PredictScale,
+ * MapPoint.cc:587-602, are applied inside).  log_scale_factor = CurrentFrame.mfLogScaleFactor.  Every occupied slot
+ * blocks (:2355-2356): pass slot_obs = 1 for all occupied keypoints.  Returns nmatches after the rotation check. */
+int orbm_search_by_projection_keyframe(orbm_t *m, const orbm_frame_t *cur, const float *scale_factors, int nlevels,
+                                       float log_scale_factor, int nKF, const uint8_t *valid, const float *Xw,
+                                       const uint8_t *mpdesc, const float *kf_angle, const float *max_dist,
+                                       const float *min_dist, const float *Tcw, int cam_type, const float *cam_params,
+                                       float th, int ORBdist, int checkOri, int32_t *slot, uint8_t *slot_obs);
+
 /* The slice of KeyFrame that SearchForTriangulation reads (host pointers).  feature vector = DBoW2::FeatureVector
  * (std::map<NodeId, std::vector<unsigned>>, FeatureVector.h:24-25) flattened in key order: node_id[k] ascending,
  * members of node k = node_idx[node_start[k] .. node_start[k+1]). */

@@ -314,6 +314,21 @@ def search_for_triangulation(K1, K2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, only_s
     return n, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
 
 
+def search_by_projection_kf(F, valid, Xw, mpdesc, kf_angle, max_dist, min_dist, Tcw, cam_type, cam_params, log_scale_factor, th, orb_dist,
+                            check_ori=True):
+    """M4 on an OracleFrame (ORBmatcher.cc:2291-2413); slot/slot_obs of F are updated in place."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    valid, Xw, mpdesc = a(valid, np.uint8), a(Xw, np.float32), a(mpdesc, np.uint8)
+    kf_angle, max_dist, min_dist = a(kf_angle, np.float32), a(max_dist, np.float32), a(min_dist, np.float32)
+    Tcw, cam_params = a(Tcw, np.float32), a(cam_params, np.float32)
+    L = lib()
+    L.orc_search_by_projection_kf.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                                                   C.c_void_p, C.c_void_p]
+    return L.orc_search_by_projection_kf(C.byref(F.f), len(valid), _p(valid), _p(Xw), _p(mpdesc), _p(kf_angle), _p(max_dist), _p(min_dist),
+                                         _p(Tcw), int(cam_type), _p(cam_params), C.c_float(log_scale_factor), C.c_float(th), int(orb_dist),
+                                         int(check_ori), _p(F.slot), _p(F.slot_obs))
+
+
 def project(cam_type, params, X, Y, Z):
     params = np.ascontiguousarray(params, dtype=np.float32)
     u, v = C.c_float(), C.c_float()

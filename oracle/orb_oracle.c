@@ -1213,3 +1213,81 @@ int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2,
   for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
   return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* M4, ORBmatcher.cc:2291-2413                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_projection_kf(orc_frame *cur, int nKF, const uint8_t *valid, const float *Xw, const uint8_t *mpdesc,
+                                const float *kfAngle, const float *maxDist, const float *minDist, const float *Tcw,
+                                int camType, const float *camParams, float logScaleFactor, float th, int ORBdist,
+                                int checkOri, int32_t *slot, uint8_t *slot_obs) {
+  int nmatches = 0;
+  const int HISTO_LENGTH = 30;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(nKF + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+  float Ow[3]; /* Ow = -Rcw.t()*tcw : generic gemm, double accumulation, alpha -1 (:2297) */
+  for (int i = 0; i < 3; i++) {
+    double sacc = 0;
+    for (int k = 0; k < 3; k++) sacc += (double)Tcw[k * 4 + i] * (double)tcw[k];
+    Ow[i] = (float)(sacc * -1.0);
+  }
+  int32_t *vIndices2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur->N > 0 ? cur->N : 1));
+  for (int i = 0; i < nKF; i++) {
+    if (!valid[i]) continue;
+    const float *x3Dw = Xw + 3 * i;
+    float x3Dc[3];
+    mat3_mul_add(Tcw, 4, x3Dw, tcw, x3Dc);
+    float uvx, uvy;
+    orc_project(camType, camParams, x3Dc[0], x3Dc[1], x3Dc[2], &uvx, &uvy);
+    if (uvx < cur->mnMinX || uvx > cur->mnMaxX) continue;
+    if (uvy < cur->mnMinY || uvy > cur->mnMaxY) continue;
+    /* PO = x3Dw-Ow; dist3D = cv::norm(PO): float subtraction, L2 norm accumulated in double (:2321-2322) */
+    double n2 = 0;
+    for (int k = 0; k < 3; k++) { float po = x3Dw[k] - Ow[k]; n2 += (double)po * (double)po; }
+    const float dist3D = (float)sqrt(n2);
+    const float maxDistance = 1.2f * maxDist[i], minDistance = 0.8f * minDist[i]; /* MapPoint.cc:552-563 */
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    /* MapPoint::PredictScale(dist3D, Frame*), MapPoint.cc:587-602 */
+    const float ratio = maxDist[i] / dist3D;
+    int nPredictedLevel = (int)ceilf(logf(ratio) / logScaleFactor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= cur->nlevels) nPredictedLevel = cur->nlevels - 1;
+    const float radius = th * cur->mvScaleFactors[nPredictedLevel];
+    int nv = orc_get_features_in_area(cur, uvx, uvy, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+    if (nv == 0) continue;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int k = 0; k < nv; k++) {
+      const int i2 = vIndices2[k];
+      if (slot[i2] >= 0) continue; /* any occupant blocks (:2355-2356) */
+      const int dist = orc_descriptor_distance(dMP, cur->desc + 32 * (size_t)i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= ORBdist) {
+      slot[bestIdx2] = i;
+      slot_obs[bestIdx2] = 1;
+      nmatches++;
+      if (checkOri) {
+        float rot = kfAngle[i] - cur->angle[bestIdx2];
+        if ((double)rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin][rotN[bin]++] = bestIdx2;
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int j = 0; j < rotN[i]; j++) { slot[rotHist[i][j]] = -1; slot_obs[rotHist[i][j]] = 0; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  free(vIndices2);
+  return nmatches;
+}

@@ -179,6 +179,15 @@ int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2,
 /* Pinhole::epipolarConstrain inputs: F12 = K1^-T [t12]x R12 K2^-1 (Pinhole.cpp:143-148), exported for tests. */
 void orc_pinhole_F12(const float *R12, const float *t12, const float *cam1, const float *cam2, float *F12);
 
+/* M4: SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist),
+ * ORBmatcher.cc:2291-2413.  KeyFrame side flattened, i in [0, nKF): valid[i] = pMP && !isBad && !sAlreadyFound.count(pMP),
+ * Xw, descriptor, kfAngle[i] = pKF->mvKeysUn[i].angle, maxDist[i]/minDist[i] = mfMaxDistance / mfMinDistance (raw; the
+ * 1.2 / 0.8 invariance factors of MapPoint.cc:552-563 are applied here).  logScaleFactor = Frame::mfLogScaleFactor. */
+int orc_search_by_projection_kf(orc_frame *cur, int nKF, const uint8_t *valid, const float *Xw, const uint8_t *mpdesc,
+                                const float *kfAngle, const float *maxDist, const float *minDist, const float *Tcw,
+                                int camType, const float *camParams, float logScaleFactor, float th, int ORBdist,
+                                int checkOri, int32_t *slot, uint8_t *slot_obs);
+
 /* M7: ComputeThreeMaxima, ORBmatcher.cc:2416-2458, on bin sizes. */
 void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 /* RadiusByViewingCos, ORBmatcher.cc:216-222. */

@@ -224,3 +224,29 @@ def test_search_for_triangulation_m6(pkg, oracle, synth, coarse, only_stereo, ch
     assert n_gpu == n_ref and n_ref > (20 if only_stereo else 60)
     assert np.array_equal(pairs_gpu, pairs_ref)
     m.close()
+
+
+@pytest.mark.parametrize("cam", [0, 1])
+def test_search_by_projection_keyframe_m4(pkg, oracle, synth, matcher, cam):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) -- relocalisation: depth-range gate,
+    MapPoint::PredictScale, +-1 level window, every occupied slot blocks, rotation check."""
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3400 + cam, cam, False)
+    rng = np.random.default_rng(77)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    dist_last = np.sqrt((Xw.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+    max_dist = (dist_last * sf[k0["octave"]]).astype(np.float32)            # MapPoint::UpdateNormalAndDepth
+    max_dist[rng.random(len(k0)) < 0.05] *= np.float32(0.3)                  # some points outside the invariance range
+    min_dist = (max_dist / sf[-1]).astype(np.float32)
+    log_sf = float(np.log(np.float32(1.2)))
+    total = 0
+    for th, orb_dist in ((10.0, 100), (3.0, 64)):                            # Tracking.cc:3877, :3891
+        F = pkg.FrameView(k1, d1, bounds)
+        OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
+        occ = rng.random(len(k1)) < 0.15
+        F.slot[occ] = 1 << 30; F.slot_obs[occ] = 1; OF.slot[occ] = 1 << 30; OF.slot_obs[occ] = 1
+        n_gpu = matcher.SearchByProjectionKeyFrame(F, sf, log_sf, has_mp, Xw, d0, k0["angle"], max_dist, min_dist, Tcw, cam, params, th, orb_dist)
+        n_ref = oracle.search_by_projection_kf(OF, has_mp, Xw, d0, k0["angle"], max_dist, min_dist, Tcw, cam, params, log_sf, th, orb_dist, True)
+        assert n_gpu == n_ref
+        assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+        total += n_ref
+    assert total > (100 if cam == 0 else 0)
