@@ -8,6 +8,8 @@
 // Replaced members (mono / rectified-stereo / RGB-D frames, Frame::Nleft == -1):
 //   int  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float th, bool bFarPoints, float thFarPoints)  :44-214
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, const Frame &Last, float th, bool bMono)                             :2027-2289
+//   int  ORBmatcher::SearchByProjection(Frame &Cur, KeyFrame *pKF, const set<MapPoint*>&, float th, int ORBdist)       :2291-2413
+//   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool, bool) :981-1222
 //   int  ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)                                                  :2463-2483
 //   void ORBmatcher::ComputeThreeMaxima(vector<int>*, int, int&, int&, int&)                                             :2416-2458
 //   float ORBmatcher::RadiusByViewingCos(const float&)                                                                   :216-222
@@ -19,6 +21,7 @@
 #include <vector>
 
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #include "orbhip.h"
 
@@ -137,6 +140,94 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     if (slot[i] >= 0 && slot[i] < nLast) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[slot[i]];      // :2162
     else if (slot[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);                     // :2279 (pruned)
   }
+  return n;
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th,
+                                   const int ORBdist) {
+  if (CurrentFrame.Nleft != -1) return SearchByProjection_ref(CurrentFrame, pKF, sAlreadyFound, th, ORBdist);
+  const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+  const int nKF = (int)vpMPs.size();
+  std::vector<uint8_t> valid(nKF, 0), desc((size_t)nKF * 32);
+  std::vector<float> Xw((size_t)nKF * 3, 0.f), ang(nKF, 0.f), dmax(nKF, 0.f), dmin(nKF, 0.f);
+  for (int i = 0; i < nKF; i++) {
+    MapPoint *pMP = vpMPs[i];
+    if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;       // :2308-2312
+    valid[i] = 1;
+    const cv::Mat x3Dw = pMP->GetWorldPos();
+    for (int k = 0; k < 3; k++) Xw[(size_t)i * 3 + k] = x3Dw.at<float>(k);
+    std::memcpy(&desc[(size_t)i * 32], pMP->GetDescriptor().ptr<uint8_t>(), 32);
+    ang[i] = pKF->mvKeysUn[i].angle;
+    dmax[i] = pMP->GetMaxDistanceInvariance() / 1.2f;                     // the C ABI takes mfMaxDistance / mfMinDistance
+    dmin[i] = pMP->GetMinDistanceInvariance() / 0.8f;
+  }
+  float Tcw[16];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) Tcw[r * 4 + c] = CurrentFrame.mTcw.at<float>(r, c);
+  const int camType = CurrentFrame.mpCamera->GetType();
+  std::vector<float> params(camType == 0 ? 4 : 8);
+  for (size_t k = 0; k < params.size(); k++) params[k] = CurrentFrame.mpCamera->getParameter((int)k);
+  std::vector<int32_t> slot(CurrentFrame.N, -1);
+  std::vector<uint8_t> sobs(CurrentFrame.N, 0);
+  for (int i = 0; i < CurrentFrame.N; i++)
+    if (CurrentFrame.mvpMapPoints[i]) { slot[i] = 1 << 30; sobs[i] = 1; }  // any occupant blocks, :2355-2356
+  const orbm_frame_t f = view_of(CurrentFrame);
+  const int n = orbm_search_by_projection_keyframe(matcher(), &f, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
+                                                   CurrentFrame.mfLogScaleFactor, nKF, valid.data(), Xw.data(), desc.data(), ang.data(),
+                                                   dmax.data(), dmin.data(), Tcw, camType, params.data(), th, ORBdist,
+                                                   mbCheckOrientation ? 1 : 0, slot.data(), sobs.data());
+  if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
+  for (int i = 0; i < CurrentFrame.N; i++)
+    if (slot[i] >= 0 && slot[i] < nKF) CurrentFrame.mvpMapPoints[i] = vpMPs[slot[i]];  // :2373
+  return n;
+}
+
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                                       const bool bOnlyStereo, const bool bCoarse) {
+  if (pKF1->mpCamera2 || pKF2->mpCamera2 || pKF1->mpCamera->GetType() != 0 || pKF2->mpCamera->GetType() != 0)
+    return SearchForTriangulation_ref(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse);  // fisheye / two-camera rigs: reference path
+  struct Flat {
+    std::vector<uint8_t> has;
+    std::vector<uint32_t> id;
+    std::vector<int32_t> start, idx;
+    orbm_keyframe_t k;
+  };
+  auto flatten = [](KeyFrame *pKF, Flat &F) {
+    F.has.resize(pKF->N);
+    for (int i = 0; i < pKF->N; i++) F.has[i] = pKF->GetMapPoint(i) != NULL;
+    F.start.push_back(0);
+    for (DBoW2::FeatureVector::const_iterator it = pKF->mFeatVec.begin(); it != pKF->mFeatVec.end(); ++it) {  // std::map: ascending ids
+      F.id.push_back(it->first);
+      for (unsigned v : it->second) F.idx.push_back((int32_t)v);
+      F.start.push_back((int32_t)F.idx.size());
+    }
+    F.k.n = pKF->N;
+    F.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(pKF->mvKeysUn.data());
+    F.k.descriptors = pKF->mDescriptors.data;
+    F.k.u_right = pKF->mvuRight.data();
+    F.k.has_mappoint = F.has.data();
+    F.k.n_nodes = (int32_t)F.id.size();
+    F.k.node_id = F.id.data(); F.k.node_start = F.start.data(); F.k.node_idx = F.idx.data();
+    F.k.scale_factors = pKF->mvScaleFactors.data(); F.k.level_sigma2 = pKF->mvLevelSigma2.data();
+    F.k.nlevels = (int32_t)pKF->mvScaleFactors.size();
+  };
+  Flat A, B;
+  flatten(pKF1, A);
+  flatten(pKF2, B);
+  auto m33 = [](const cv::Mat &M, float *o) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o[3 * r + c] = M.at<float>(r, c); };
+  auto v3 = [](const cv::Mat &M, float *o) { for (int r = 0; r < 3; r++) o[r] = M.at<float>(r); };
+  float R1w[9], R2w[9], t1w[3], t2w[3], Cw[3], cam1[4], cam2[4];
+  m33(pKF1->GetRotation(), R1w); m33(pKF2->GetRotation(), R2w);
+  v3(pKF1->GetTranslation(), t1w); v3(pKF2->GetTranslation(), t2w); v3(pKF1->GetCameraCenter(), Cw);
+  for (int k = 0; k < 4; k++) { cam1[k] = pKF1->mpCamera->getParameter(k); cam2[k] = pKF2->mpCamera->getParameter(k); }
+  std::vector<int32_t> m12(pKF1->N, -1);
+  const int n = orbm_search_for_triangulation(matcher(), &A.k, &B.k, R1w, t1w, R2w, t2w, Cw, cam1, cam2, bOnlyStereo, bCoarse,
+                                              mbCheckOrientation ? 1 : 0, m12.data());
+  if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(n);
+  for (size_t i = 0; i < m12.size(); i++)
+    if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));  // :1211-1219
   return n;
 }
 
