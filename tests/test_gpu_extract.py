@@ -199,3 +199,31 @@ def test_full_size_properties(pkg, frame):
         assert n == cnt[i % 8, 0] and np.array_equal(kps[i, :n], kps[i % 8, :n]) and np.array_equal(desc[i, :n], desc[i % 8, :n])
     assert (cnt[:, 0] >= 1000).all() and (cnt[:, 0] <= cap).all()
     e.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(H=376, W=1241, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),    # KITTI (Examples/Monocular/KITTI00-02.yaml)
+    dict(H=480, W=640, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),     # TUM RGB-D (TUM1.yaml)
+    dict(H=300, W=402, nfeatures=300, scaleFactor=1.5, nlevels=5, iniThFAST=12, minThFAST=4),      # other scale factor / level count
+    dict(H=256, W=300, nfeatures=64, scaleFactor=2.0, nlevels=3, iniThFAST=30, minThFAST=30),      # octave pyramid, ini == min threshold
+    dict(H=200, W=260, nfeatures=20, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),       # tiny quotas (some levels get 1-2 features)
+    dict(H=130, W=150, nfeatures=500, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),      # upper levels smaller than one cell
+])
+def test_extract_parity_config_matrix(pkg, oracle, synth, cfg):
+    """Geometry / parameter sweep: other datasets' image sizes, scale factors, level counts, thresholds, quotas."""
+    cfg = dict(cfg)
+    H, W = cfg.pop("H"), cfg.pop("W")
+    img = synth.make_frame(4000 + H, H, W)
+    e = pkg.ORBextractor(**cfg)
+    o = oracle.OracleExtractor(**cfg)
+    for lap in [(0, 1000), (0, 0)]:
+        mono, kps, desc = e(img, None, lap)
+        mono_r, kps_r, desc_r = o.extract(img, lap)
+        assert mono == mono_r
+        assert_kps_equal(kps, kps_r)
+        assert np.array_equal(desc, desc_r)
+    nl = cfg["nlevels"]
+    pyr = o.pyramid(img)
+    for l in range(nl):
+        assert np.array_equal(e.image_pyramid_level(l), pyr[l])
+    e.close()
