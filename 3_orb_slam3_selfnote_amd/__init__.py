@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -114,6 +114,7 @@ def load(build_if_needed=True):
                                                          vp, vp, vp, vp, vp, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
+    L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
     L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, i32, i32, vp, vp]
     L.orbm_search_by_projection_last_frame.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32,
                                                        i32, i32, vp, vp]
@@ -451,6 +452,23 @@ class ORBmatcher:
         self._check(rc, "orbm_search_by_projection_keyframe")
         if rc < 0:
             raise OrbError("orbm_search_by_projection_keyframe rc=%d" % rc)
+        return rc
+
+    def SearchByProjectionSim3(self, KF, scale_factors, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Scw, cam, th,
+                               ratioHamming=1.0):
+        """SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th, ratioHamming) -- ORBmatcher.cc:489-720.
+        KF is a FrameView of the keyframe's keypoints; KF.slot plays vpMatched."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf = a(scale_factors, np.float32)
+        valid, Xw, normal, mp_desc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mp_desc, np.uint8)
+        max_dist, min_dist, Scw, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Scw, np.float32), a(cam, np.float32)
+        fs = KF.struct()
+        rc = self.L.orbm_search_by_projection_sim3(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), len(valid), _p(valid),
+                                                   _p(Xw), _p(normal), _p(mp_desc), _p(max_dist), _p(min_dist), _p(Scw), _p(cam), int(th),
+                                                   C.c_float(ratioHamming), _p(KF.slot), _p(KF.slot_obs))
+        self._check(rc, "orbm_search_by_projection_sim3")
+        if rc < 0:
+            raise OrbError("orbm_search_by_projection_sim3 rc=%d" % rc)
         return rc
 
     def SearchForTriangulation(self, KF1, KF2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, bOnlyStereo=False, bCoarse=False):

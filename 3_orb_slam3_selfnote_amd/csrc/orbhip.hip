@@ -937,6 +937,66 @@ int orbm_search_by_projection_keyframe(orbm_t *m, const orbm_frame_t *cur, const
   return prune_by_rotation(nKF, moq.data(), kf_angle, cur->keys_un, slot, slot_obs, nmatches);
 }
 
+int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const float *sf, int nlevels, float logScaleFactor, int nP,
+                                   const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                                   const float *max_dist, const float *min_dist, const float *Scw, const float *cam, int th,
+                                   float ratioHamming, int32_t *slot, uint8_t *slot_obs) {
+  if (!m || !kf || !sf || nlevels < 1 || nP < 0 || !Scw || !cam || !slot || !slot_obs) return ORBX_E_ARG;
+  if (nP > 0 && (!valid || !Xw || !normal || !mpdesc || !max_dist || !min_dist)) return ORBX_E_ARG;
+  // Decompose Scw, :498-503: scw = sqrt(row0 . row0) (Mat::dot accumulates in double); Rcw = sRcw/scw, tcw = t/scw
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)sqrt(dot);
+  const double inv = 1. / (double)scw;
+  float T[16] = {0};  // row-major [Rcw | tcw] so that the shared 3x3*3x1+t helper applies
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)((double)Scw[4 * i + j] * inv);
+    T[4 * i + 3] = (float)((double)Scw[4 * i + 3] * inv);
+  }
+  const float tcw[3] = {T[3], T[7], T[11]};
+  float Ow[3];
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)T[4 * k + i] * (double)tcw[k];
+    Ow[i] = (float)(-acc);
+  }
+  std::vector<float> u(nP, 0.f), v(nP, 0.f), rad(nP, 0.f);
+  std::vector<int32_t> minl(nP, -1), maxl(nP, -1);
+  std::vector<uint8_t> flags(nP, 0);
+  for (int i = 0; i < nP; i++) {
+    if (!valid[i]) continue;
+    const float *p3Dw = Xw + 3 * i;
+    float p3Dc[3];
+    mat3_mul_add(T, p3Dw, tcw, p3Dc);                                         // :523
+    if ((double)p3Dc[2] < 0.0) continue;                                      // :526
+    float ux, vy;
+    orbm_project(0, cam, p3Dc[0], p3Dc[1], p3Dc[2], &ux, &vy);                // :534
+    if (!(ux >= kf->min_x && ux < kf->max_x && vy >= kf->min_y && vy < kf->max_y)) continue;  // KeyFrame::IsInImage, KeyFrame.cc:844-847
+    float PO[3];
+    double n2 = 0, pd = 0;
+    for (int k = 0; k < 3; k++) { PO[k] = p3Dw[k] - Ow[k]; n2 += (double)PO[k] * (double)PO[k]; }
+    const float dist = (float)sqrt(n2);                                       // cv::norm, :544
+    if (dist < 0.8f * min_dist[i] || dist > 1.2f * max_dist[i]) continue;     // :546
+    for (int k = 0; k < 3; k++) pd += (double)PO[k] * (double)normal[3 * i + k];
+    if (pd < 0.5 * (double)dist) continue;                                    // :552
+    const float ratio = max_dist[i] / dist;                                   // MapPoint::PredictScale(dist, pKF), MapPoint.cc:570-585
+    int lvl = (int)ceilf(logf(ratio) / logScaleFactor);
+    lvl = lvl < 0 ? 0 : (lvl >= nlevels ? nlevels - 1 : lvl);
+    u[i] = ux; v[i] = vy;
+    rad[i] = (float)th * sf[lvl];                                             // :558
+    minl[i] = lvl - 1; maxl[i] = lvl;                                         // :579-580
+    flags[i] = 3;
+  }
+  orbm_queries_t q;
+  q.nq = nP; q.descriptors = mpdesc; q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = nullptr; q.flags = flags.data();
+  orbm_frame_t f = *kf;
+  f.u_right = nullptr;
+  // bestDist <= TH_LOW*ratioHamming with an int on the left: same as bestDist <= floor(50.f*ratioHamming)
+  const int th_dist = (int)floorf((float)ORBM_TH_LOW * ratioHamming);
+  return orbm_search_by_projection(m, &f, &q, 0.f, th_dist, 0, slot, slot_obs, nullptr, nullptr);
+}
+
 // ---- SearchForTriangulation (ORBmatcher.cc:981-1222), Pinhole / Pinhole, no second camera --------------------------------
 namespace {
 // cv::Mat algebra of ORBmatcher.cc:988-1010 and Pinhole.cpp:143-148 restated ([OPENCV-UNVERIFIED]):

@@ -205,6 +205,19 @@ int orbm_search_by_projection_keyframe(orbm_t *m, const orbm_frame_t *cur, const
                                        const float *min_dist, const float *Tcw, int cam_type, const float *cam_params,
                                        float th, int ORBdist, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints,
+ *                                    vector<MapPoint*> &vpMatched, int th, float ratioHamming)   (ORBmatcher.cc:489-602)
+ * and its :604-720 overload (which only stores one more pointer per match), flattened, host pointers.
+ * kf = the keyframe's mvKeysUn / mDescriptors / image bounds; i in [0, nP): valid[i] = !pMP->isBad() &&
+ * !spAlreadyFound.count(pMP); Xw = GetWorldPos(); normal = GetNormal(); max_dist / min_dist = mfMaxDistance /
+ * mfMinDistance; Scw row-major 4x4 (Sim3); cam = {fx, fy, cx, cy}; log_scale_factor = pKF->mfLogScaleFactor.
+ * slot (in/out) = vpMatched as candidate-point index or -1; every occupied slot blocks (:577-578).  Returns nmatches. */
+int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels,
+                                   float log_scale_factor, int nP, const uint8_t *valid, const float *Xw,
+                                   const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                                   const float *min_dist, const float *Scw, const float *cam, int th,
+                                   float ratioHamming, int32_t *slot, uint8_t *slot_obs);
+
 /* The slice of KeyFrame that SearchForTriangulation reads (host pointers).  feature vector = DBoW2::FeatureVector
  * (std::map<NodeId, std::vector<unsigned>>, FeatureVector.h:24-25) flattened in key order: node_id[k] ascending,
  * members of node k = node_idx[node_start[k] .. node_start[k+1]). */

@@ -329,6 +329,17 @@ def search_by_projection_kf(F, valid, Xw, mpdesc, kf_angle, max_dist, min_dist, 
                                          int(check_ori), _p(F.slot), _p(F.slot_obs))
 
 
+def search_by_projection_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th, ratio_hamming):
+    """M5 on an OracleFrame holding the KeyFrame's keypoints (ORBmatcher.cc:489-602); slot/slot_obs updated in place."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    valid, Xw, normal, mpdesc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mpdesc, np.uint8)
+    max_dist, min_dist, Scw, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Scw, np.float32), a(cam, np.float32)
+    L = lib()
+    L.orc_search_by_projection_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    return L.orc_search_by_projection_sim3(C.byref(F.f), len(valid), _p(valid), _p(Xw), _p(normal), _p(mpdesc), _p(max_dist), _p(min_dist),
+                                           _p(Scw), _p(cam), C.c_float(log_scale_factor), int(th), C.c_float(ratio_hamming), _p(F.slot), _p(F.slot_obs))
+
+
 def project(cam_type, params, X, Y, Z):
     params = np.ascontiguousarray(params, dtype=np.float32)
     u, v = C.c_float(), C.c_float()

@@ -1291,3 +1291,71 @@ int orc_search_by_projection_kf(orc_frame *cur, int nKF, const uint8_t *valid, c
   free(vIndices2);
   return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* M5, ORBmatcher.cc:489-602                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal,
+                                  const uint8_t *mpdesc, const float *maxDist, const float *minDist, const float *Scw,
+                                  const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
+                                  uint8_t *slot_obs) {
+  /* Decompose Scw (:498-503): Mat::dot accumulates in double; Mat / float = convert with scale 1./s in double */
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)sqrt(dot);
+  const double inv = 1. / (double)scw;
+  float Rcw[9], tcw[3], Ow[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) Rcw[i * 3 + j] = (float)((double)Scw[i * 4 + j] * inv);
+    tcw[i] = (float)((double)Scw[i * 4 + 3] * inv);
+  }
+  for (int i = 0; i < 3; i++) {
+    double sacc = 0;
+    for (int k = 0; k < 3; k++) sacc += (double)Rcw[k * 3 + i] * (double)tcw[k];
+    Ow[i] = (float)(sacc * -1.0);
+  }
+  int nmatches = 0;
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kf->N > 0 ? kf->N : 1));
+  for (int iMP = 0; iMP < nP; iMP++) {
+    if (!valid[iMP]) continue;
+    const float *p3Dw = Xw + 3 * iMP;
+    float p3Dc[3];
+    mat3_mul_add(Rcw, 3, p3Dw, tcw, p3Dc);
+    if ((double)p3Dc[2] < 0.0) continue;
+    float uvx, uvy;
+    orc_project(0, cam, p3Dc[0], p3Dc[1], p3Dc[2], &uvx, &uvy);
+    if (!(uvx >= kf->mnMinX && uvx < kf->mnMaxX && uvy >= kf->mnMinY && uvy < kf->mnMaxY)) continue; /* KeyFrame::IsInImage */
+    const float maxDistance = 1.2f * maxDist[iMP], minDistance = 0.8f * minDist[iMP];
+    float PO[3];
+    double n2 = 0, pd = 0;
+    for (int k = 0; k < 3; k++) { PO[k] = p3Dw[k] - Ow[k]; n2 += (double)PO[k] * (double)PO[k]; }
+    const float dist = (float)sqrt(n2);
+    if (dist < minDistance || dist > maxDistance) continue;
+    for (int k = 0; k < 3; k++) pd += (double)PO[k] * (double)normal[3 * iMP + k];
+    if (pd < 0.5 * (double)dist) continue;                     /* viewing angle < 60 deg, :553 */
+    const float ratio = maxDist[iMP] / dist;                   /* PredictScale(dist, pKF), MapPoint.cc:570-585 */
+    int nPredictedLevel = (int)ceilf(logf(ratio) / logScaleFactor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= kf->nlevels) nPredictedLevel = kf->nlevels - 1;
+    const float radius = (float)th * kf->mvScaleFactors[nPredictedLevel];
+    int nv = orc_get_features_in_area(kf, uvx, uvy, radius, -1, -1, vIndices); /* KeyFrame::GetFeaturesInArea: no level filter */
+    if (nv == 0) continue;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)iMP;
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nv; k++) {
+      const int idx = vIndices[k];
+      if (slot[idx] >= 0) continue;
+      const int kpLevel = kf->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int d = orc_descriptor_distance(dMP, kf->desc + 32 * (size_t)idx);
+      if (d < bestDist) { bestDist = d; bestIdx = idx; }
+    }
+    if ((float)bestDist <= 50 /* TH_LOW */ * ratioHamming) {
+      slot[bestIdx] = iMP;
+      slot_obs[bestIdx] = 1;
+      nmatches++;
+    }
+  }
+  free(vIndices);
+  return nmatches;
+}

@@ -188,6 +188,15 @@ int orc_search_by_projection_kf(orc_frame *cur, int nKF, const uint8_t *valid, c
                                 int camType, const float *camParams, float logScaleFactor, float th, int ORBdist,
                                 int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* M5: SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched,
+ * int th, float ratioHamming), ORBmatcher.cc:489-602 (the :604-720 overload only stores one more pointer per match).
+ * kf = the keyframe's keypoints/grid; i in [0, nP): valid[i] = !isBad && !spAlreadyFound.count(pMP); Xw, normal (GetNormal()),
+ * descriptor, maxDist/minDist raw.  Scw row-major 4x4.  Pinhole camera [fx,fy,cx,cy].  slot = vpMatched (any occupant blocks). */
+int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal,
+                                  const uint8_t *mpdesc, const float *maxDist, const float *minDist, const float *Scw,
+                                  const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
+                                  uint8_t *slot_obs);
+
 /* M7: ComputeThreeMaxima, ORBmatcher.cc:2416-2458, on bin sizes. */
 void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 /* RadiusByViewingCos, ORBmatcher.cc:216-222. */

@@ -250,3 +250,30 @@ def test_search_by_projection_keyframe_m4(pkg, oracle, synth, matcher, cam):
         assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
         total += n_ref
     assert total > (100 if cam == 0 else 0)
+
+
+@pytest.mark.parametrize("ratio", [1.0, 0.75])
+def test_search_by_projection_sim3_m5(pkg, oracle, synth, matcher, ratio):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) -- loop closing: Sim3
+    decomposition, IsInImage (half-open), depth-range and viewing-angle gates, PredictScale, [lvl-1, lvl] window."""
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3500, 0, False)
+    rng = np.random.default_rng(31)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    scale = np.float32(1.37)
+    Scw = Tcw.copy()
+    Scw[:3, :] *= scale                                                        # s [R | t]
+    dist_last = np.sqrt((Xw.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+    max_dist = (dist_last * sf[k0["octave"]]).astype(np.float32)
+    min_dist = (max_dist / sf[-1]).astype(np.float32)
+    normal = (Xw / np.maximum(np.linalg.norm(Xw, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    flip = rng.random(len(k0)) < 0.1
+    normal[flip] *= np.float32(-1)                                             # seen from behind: fails the 60-degree gate
+    log_sf = float(np.log(np.float32(1.2)))
+    KF = pkg.FrameView(k1, d1, bounds)
+    OKF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
+    occ = rng.random(len(k1)) < 0.2
+    KF.slot[occ] = 1 << 30; KF.slot_obs[occ] = 1; OKF.slot[occ] = 1 << 30; OKF.slot_obs[occ] = 1
+    n_gpu = matcher.SearchByProjectionSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 8, ratio)
+    n_ref = oracle.search_by_projection_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 8, ratio)
+    assert n_gpu == n_ref and n_ref > 100
+    assert np.array_equal(KF.slot, OKF.slot) and np.array_equal(KF.slot_obs, OKF.slot_obs)
