@@ -699,19 +699,29 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   int pitch;
   const uint8_t *img = level_plane(P, frame, level, pitch);
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
-  for (int idx = tid; idx < 38 * 34; idx += 256) {
-    const int r = idx / 34, c = idx - r * 34;
-    const int yy = reflect101(y0 + r - 3, G.h);
-    const int xb = x0 - 4 + 4 * c;
-    const uint8_t *row = img + (size_t)yy * pitch;
-    uint32_t v;
-    if (aligned && xb >= 0 && xb + 3 < G.w) {
-      v = *reinterpret_cast<const uint32_t *>(row + xb);
-    } else {
-      v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
-          ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
+  // interior tiles (the majority): no reflection anywhere, plain coalesced dword rows.  Decided once per workgroup.
+  const bool interior = aligned && x0 >= 4 && x0 + BLUR_TX + 4 <= G.w && y0 >= 3 && y0 + BLUR_TY + 3 <= G.h;
+  if (interior) {
+    const uint8_t *base = img + (size_t)(y0 - 3) * pitch + (x0 - 4);
+    for (int idx = tid; idx < 38 * 34; idx += 256) {
+      const int r = idx / 34, c = idx - r * 34;
+      sIn[idx] = *reinterpret_cast<const uint32_t *>(base + (size_t)r * pitch + 4 * c);
     }
-    sIn[idx] = v;
+  } else {
+    for (int idx = tid; idx < 38 * 34; idx += 256) {
+      const int r = idx / 34, c = idx - r * 34;
+      const int yy = reflect101(y0 + r - 3, G.h);
+      const int xb = x0 - 4 + 4 * c;
+      const uint8_t *row = img + (size_t)yy * pitch;
+      uint32_t v;
+      if (aligned && xb >= 0 && xb + 3 < G.w) {
+        v = *reinterpret_cast<const uint32_t *>(row + xb);
+      } else {
+        v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
+            ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
+      }
+      sIn[idx] = v;
+    }
   }
   __syncthreads();
   // horizontal pass: thread = 4 consecutive outputs of one row; taps as two byte-quads for v_dot4_u32_u8

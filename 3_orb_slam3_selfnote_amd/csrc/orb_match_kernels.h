@@ -153,6 +153,9 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   K top[MATCH_TOPK];
 #pragma unroll
   for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
+  // GetFeaturesInArea's level filter (Frame.cc:779, :794-801) as a closed interval; open ends when it is disabled
+  const int minlE = w.live && w.checkLevels ? w.minl : -1000;
+  const int maxlE = w.live && w.checkLevels && w.maxl >= 0 ? w.maxl : 1000;
   for (int base = 0; base < n; base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
     __syncthreads();
@@ -172,7 +175,15 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
     if (w.live) {
       for (int c = 0; c < m; c++) {
         const CandMeta cm = sMeta[c];
-        if (cand_passes(w, cm.x, cm.y, cm.bits, cm.ur)) {
+        // cand_passes() in sign-bit arithmetic (one compare at the end instead of a dozen compare/and chains):
+        // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
+        const int gx = (cm.bits >> 8) & 0xff, gy = (cm.bits >> 16) & 0xff, oct = cm.bits & 0xff;
+        int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct);
+        viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
+        const int fpass = __float_as_int(fabsf(cm.x - w.u) - w.r) & __float_as_int(fabsf(cm.y - w.v) - w.r);
+        bool ok = (fpass & ~viol) < 0;
+        if (w.stereo) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);   // ORBmatcher.cc:93-98, :2139-2146
+        if (ok) {
           const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
           const int dist = __popc(a.x ^ qd[0]) + __popc(a.y ^ qd[1]) + __popc(a.z ^ qd[2]) + __popc(a.w ^ qd[3]) +
                            __popc(b.x ^ qd[4]) + __popc(b.y ^ qd[5]) + __popc(b.z ^ qd[6]) + __popc(b.w ^ qd[7]);
