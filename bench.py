@@ -55,12 +55,12 @@ def cpu_baseline(frames, offs, budget_s=12.0):
     prev = None
     t0 = time.perf_counter()
     n = 0
-    for t in range(len(frames)):
+    for t in list(range(len(frames))) * 4:                              # cycle the stream until the time budget is used
         mono, kps, desc = ex.extract(frames[t], LAP)
         if prev is not None and len(kps):
             pk, pd, po = prev
             F = O.OracleFrame(kps["x"], kps["y"], kps["octave"], kps["angle"], desc, (0.0, float(W), 0.0, float(H)), sf)
-            u = (pk["x"] + np.float32(po[0] - offs[t][0])).astype(np.float32)
+            u = (pk["x"] + np.float32(po[0] - offs[t][0])).astype(np.float32)  # (wrap-around pair at t == 0: large shift, still a valid query set)
             v = (pk["y"] + np.float32(po[1] - offs[t][1])).astype(np.float32)
             m1 = np.full(len(pk), -1, np.int32)
             F.search_by_projection_win(pd, u, v, np.full(len(pk), 1.0e4, np.float32), m1, m1, 0.8, 100, True)
@@ -89,14 +89,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; backend "nccl" (= RCCL) for the barrier / MAX-time all-reduce.  ORB_BENCH_BACKEND=gloo lets several
+    # ranks rehearse the N>1 path on a box with fewer GPUs (ranks then share devices modulo the device count).
+    backend = os.environ.get("ORB_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
     pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
 
@@ -181,7 +188,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
