@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
-    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
+    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
 
@@ -122,6 +122,8 @@ def load(build_if_needed=True):
     L.orbm_radius_by_viewing_cos.restype = f32
     L.orbm_radius_by_viewing_cos.argtypes = [f32]
     L.orbm_project.argtypes = [i32, vp, f32, f32, f32, vp, vp]
+    L.orbm_undistort_keypoints.argtypes = [i32, vp, vp, vp, i32, vp]
+    L.orbm_image_bounds.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, vp]
     L.orbm_set_profiling.argtypes = [vp, i32]
     L.orbm_get_last_ms.restype = f32
     L.orbm_get_last_ms.argtypes = [vp]
@@ -504,6 +506,23 @@ class ORBmatcher:
         ms = np.zeros(2, dtype=np.float32)
         n = self.L.orbm_get_stage_ms(self.m, _p(ms), 2)
         return dict(zip(["match_scan", "match_resolve"], ms[:n].tolist()))
+
+
+def undistort_keypoints(keys, K, D):
+    """Frame::UndistortKeyPoints (Frame.cc:837-870): mvKeys -> mvKeysUn."""
+    keys = np.ascontiguousarray(keys, dtype=KP_DTYPE)
+    K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)
+    out = np.zeros_like(keys)
+    load().orbm_undistort_keypoints(len(keys), _p(keys), _p(K), _p(D), len(D), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K, D):
+    """Frame::ComputeImageBounds (Frame.cc:872-899): (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)
+    v = [C.c_float() for _ in range(4)]
+    load().orbm_image_bounds(int(cols), int(rows), _p(K), _p(D), len(D), *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
 
 
 def project(cam_type, params, X, Y, Z):

@@ -650,6 +650,46 @@ void orbm_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3)
 
 float orbm_radius_by_viewing_cos(float viewCos) { return ((double)viewCos > 0.998) ? 2.5f : 4.0f; }  // ORBmatcher.cc:216-222
 
+// cv::undistortPoints with R = I, P = K (Frame.cc:856, :883): 5 fixed-point iterations in double
+static void undistort_one(double u, double v, const float *K, const float *D, int nD, float *ou, float *ov) {
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = nD > 4 ? D[4] : 0.0;
+  double x = (u - cx) * (1. / fx), y = (v - cy) * (1. / fy);
+  const double x0 = x, y0 = y;
+  for (int it = 0; it < 5; it++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+    const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+    const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  *ou = (float)(x * fx + cx);
+  *ov = (float)(y * fy + cy);
+}
+
+void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K, const float *D, int nD, orbx_keypoint_t *keys_un) {
+  for (int i = 0; i < n; i++) {
+    orbx_keypoint_t k = keys[i];
+    if (D[0] != 0.0f) undistort_one((double)keys[i].x, (double)keys[i].y, K, D, nD, &k.x, &k.y);
+    keys_un[i] = k;
+  }
+}
+
+void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *min_x, float *max_x, float *min_y, float *max_y) {
+  if (D[0] != 0.0f) {
+    const float c[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+    float o[4][2];
+    for (int i = 0; i < 4; i++) undistort_one((double)c[i][0], (double)c[i][1], K, D, nD, &o[i][0], &o[i][1]);
+    *min_x = std::min(o[0][0], o[2][0]);
+    *max_x = std::max(o[1][0], o[3][0]);
+    *min_y = std::min(o[0][1], o[1][1]);
+    *max_y = std::max(o[2][1], o[3][1]);
+  } else {
+    *min_x = 0.0f; *max_x = (float)cols; *min_y = 0.0f; *max_y = (float)rows;
+  }
+}
+
 void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float *u, float *v) {
   if (cam_type == 0) {  // Pinhole.cpp:46-49
     *u = p[0] * X / Z + p[2];

@@ -261,6 +261,15 @@ float orbm_radius_by_viewing_cos(float viewCos);
  * (KannalaBrandt8.cpp:29-45); params = mvParameters. */
 void orbm_project(int cam_type, const float *params, float X, float Y, float Z, float *u, float *v);
 
+/* Frame::UndistortKeyPoints (Frame.cc:837-870) and Frame::ComputeImageBounds (:872-899): the step between extract and
+ * match.  cv::undistortPoints(pts, K, D, R = I, P = K) is an fp64 fixed-point iteration on <= N points, so it
+ * stays on the host.  K = {fx, fy, cx, cy}; D = {k1, k2, p1, p2[, k3]} (nD = 4 or 5).
+ * D[0] == 0 copies the keypoints unchanged (Frame.cc:839-843) and gives the bounds [0,cols] x [0,rows].
+ * keys_un may alias keys (only pt is rewritten). */
+void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K, const float *D, int nD, orbx_keypoint_t *keys_un);
+void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *min_x, float *max_x, float *min_y,
+                       float *max_y);
+
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */
 void orbm_set_profiling(orbm_t *m, int enable);
 float orbm_get_last_ms(orbm_t *m);

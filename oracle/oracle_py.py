@@ -340,6 +340,25 @@ def search_by_projection_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, 
                                            _p(Scw), _p(cam), C.c_float(log_scale_factor), int(th), C.c_float(ratio_hamming), _p(F.slot), _p(F.slot_obs))
 
 
+def undistort_points(xy, K, D):
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)
+    out = np.zeros_like(xy)
+    L = lib()
+    L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_undistort_points(len(xy), _p(xy), _p(K), _p(D), len(D), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K, D):
+    K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)
+    v = [C.c_float() for _ in range(4)]
+    L = lib()
+    L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    L.orc_image_bounds(cols, rows, _p(K), _p(D), len(D), *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
 def project(cam_type, params, X, Y, Z):
     params = np.ascontiguousarray(params, dtype=np.float32)
     u, v = C.c_float(), C.c_float()

@@ -1359,3 +1359,40 @@ int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, c
   free(vIndices);
   return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* G0: cv::undistortPoints as used by Frame.cc:856 / :883 [OPENCV-UNVERIFIED]   */
+/* ------------------------------------------------------------------------------------------ */
+void orc_undistort_points(int n, const float *xy_in, const float *K, const float *D, int nD, float *xy_out) {
+  if (D[0] == 0.0f) { memcpy(xy_out, xy_in, sizeof(float) * 2 * (size_t)n); return; }
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = nD > 4 ? D[4] : 0.0;
+  const double ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; i++) {
+    double x = ((double)xy_in[2 * i] - cx) * ifx, y = ((double)xy_in[2 * i + 1] - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      double r2 = x * x + y * y;
+      double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    xy_out[2 * i] = (float)(x * fx + cx);      /* P = K */
+    xy_out[2 * i + 1] = (float)(y * fy + cy);
+  }
+}
+
+void orc_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *minX, float *maxX, float *minY, float *maxY) {
+  if (D[0] != 0.0f) {
+    float in[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows}, out[8];
+    orc_undistort_points(4, in, K, D, nD, out);
+    *minX = out[0] < out[4] ? out[0] : out[4];
+    *maxX = out[2] > out[6] ? out[2] : out[6];
+    *minY = out[1] < out[3] ? out[1] : out[3];
+    *maxY = out[5] > out[7] ? out[5] : out[7];
+  } else {
+    *minX = 0.0f; *maxX = (float)cols; *minY = 0.0f; *maxY = (float)rows;
+  }
+}

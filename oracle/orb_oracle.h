@@ -197,6 +197,13 @@ int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, c
                                   const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
                                   uint8_t *slot_obs);
 
+/* G0: Frame::UndistortKeyPoints (Frame.cc:837-870) / ComputeImageBounds (:872-899) =
+ * cv::undistortPoints(src, dst, K, D=(k1,k2,p1,p2[,k3]), R=I, P=K) restated from SURVEY.md A.9: per point in double,
+ * 5 fixed-point iterations, result stored as float.  K = [fx,fy,cx,cy]; D has nD = 4 or 5 coefficients.
+ * If D[0] == 0 the reference copies the keypoints unchanged (Frame.cc:839-843). */
+void orc_undistort_points(int n, const float *xy_in, const float *K, const float *D, int nD, float *xy_out);
+void orc_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *minX, float *maxX, float *minY, float *maxY);
+
 /* M7: ComputeThreeMaxima, ORBmatcher.cc:2416-2458, on bin sizes. */
 void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 /* RadiusByViewingCos, ORBmatcher.cc:216-222. */
