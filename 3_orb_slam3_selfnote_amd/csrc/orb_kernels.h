@@ -253,14 +253,16 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
 // brighter than v+t.  Pixels that fail it at minThFAST have S <= minThFAST and can never be emitted nor suppress a
 // neighbour, so their score is left at 0 and the 16-pixel score is only evaluated for the survivors.
 __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
+  // sign-bit arithmetic (no compare -> select chains, which cost SGPR hazards and scalar mask ops)
   constexpr int Pt = FAST_TILE_PITCH;
   const int v = c[0];
   const int p0 = c[3 * Pt], p4 = c[3], p8 = c[-3 * Pt], p12 = c[-3];
   const int lo = v - t, hi = v + t;
-  const uint32_t d = (p0 < lo ? 1u : 0u) | (p4 < lo ? 2u : 0u) | (p8 < lo ? 4u : 0u) | (p12 < lo ? 8u : 0u);
-  const uint32_t b = (p0 > hi ? 1u : 0u) | (p4 > hi ? 2u : 0u) | (p8 > hi ? 4u : 0u) | (p12 > hi ? 8u : 0u);
-  const uint32_t dr = d | (d << 4), br = b | (b << 4);  // rotate: adjacency incl. 12 -> 0
-  return ((dr & (dr >> 1)) | (br & (br >> 1))) & 0xfu;
+  const int d0 = p0 - lo, d4 = p4 - lo, d8 = p8 - lo, d12 = p12 - lo;   // negative <=> darker than v - t
+  const int b0 = hi - p0, b4 = hi - p4, b8 = hi - p8, b12 = hi - p12;   // negative <=> brighter than v + t
+  const int dd = (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
+  const int bb = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+  return (dd | bb) < 0;
 }
 
 __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     const unsigned long long b = __ballot(pass);
     uint32_t wbase = 0;
     if (lane == 0 && b) wbase = atomicAdd(&sNList, (uint32_t)__popcll(b));
-    wbase = __shfl(wbase, 0, WAVE);
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
     if (pass) sList[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
   }
   __syncthreads();

@@ -363,12 +363,15 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     for (int base = 0; base < nq; base += 64) {
       const int q = base + lane;
       K tk[MATCH_TOPK];
+      int eidx[MATCH_TOPK];       // keypoint index of entry j, -1 for an empty entry
       uint32_t cm = 0, oct4 = 0;  // bit j: entry j of my list is claimed; 4 bits per entry: its octave
 #pragma unroll
       for (int j = 0; j < MATCH_TOPK; j++) {
         tk[j] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+        eidx[j] = -1;
         if (tk[j] != KT::NONE) {
           const int idx = KT::idx(tk[j]);
+          eidx[j] = idx;
           cm |= ((sClaim[idx >> 5] >> (idx & 31)) & 1u) << j;
           oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
         }
@@ -414,8 +417,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           if (ob) {  // lanes whose list contains the claimed keypoint re-decide
             uint32_t ncm = cm;
 #pragma unroll
-            for (int j = 0; j < MATCH_TOPK; j++)
-              if (tk[j] != KT::NONE && KT::idx(tk[j]) == bestIdx) ncm |= 1u << j;
+            for (int j = 0; j < MATCH_TOPK; j++) ncm |= (eidx[j] == bestIdx ? 1u : 0u) << j;
             if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
           }
         }
