@@ -17,7 +17,7 @@ import numpy as np
 from . import build as _build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liborbhip.so")
+LIB_PATH = os.environ.get("ORBHIP_LIB", os.path.join(HERE, "liborbhip.so"))  # ORBHIP_LIB: diagnostic builds only
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -71,7 +71,7 @@ def load(build_if_needed=True):
         import torch  # noqa: F401
     except Exception:
         pass
-    if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc"):
+    if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc") and "ORBHIP_LIB" not in os.environ:
         _build.build()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("liborbhip.so is not built (run __graft_entry__.build()); there is no CPU fallback")

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const int syLast = min(max(P.ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), Gs.h - 1);
   const int nsrc = syLast - syFirst + 1;
   int2 *sX = reinterpret_cast<int2 *>(smem_rs);                       // [G.w]
-  uint8_t *sRows = smem_rs + (((size_t)G.w * 8 + 15) & ~(size_t)15);   // [nsrc][smemRowBytes]
+  const size_t sRowsOff = ((size_t)G.w * 8 + 15) & ~(size_t)15;
+  uint8_t *sRows = smem_rs + sRowsOff;   // [nsrc][smemRowBytes]
   for (int i = tid; i < G.w; i += 256) sX[i] = P.xtab[G.xtabBase + i];
   const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
   if (nsrc <= RESIZE_MAXSRC) {
@@ -178,33 +179,37 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
   const int qw = (G.w + 3) >> 2;
   const uint32_t mq = 0xffffffffu / (uint32_t)qw + 1u;
-  for (int q = tid; q < qw * nrows; q += 256) {
-    const int ry = (int)__umulhi((uint32_t)q, mq), dx0 = (q - ry * qw) * 4, dy = dy0 + ry;
-    const int2 yt = P.ytab[G.ytabBase + dy];
-    const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
-    const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
-    const uint8_t *S0, *S1;
-    if (nsrc <= RESIZE_MAXSRC) { S0 = sRows + (size_t)(sy0 - syFirst) * smemRowBytes; S1 = sRows + (size_t)(sy1 - syFirst) * smemRowBytes; }
-    else { S0 = src + (size_t)sy0 * spitch; S1 = src + (size_t)sy1 * spitch; }  // extreme scale factors: straight from global
-    uint32_t packed = 0;
+  // The row loop is instantiated twice so that the source gathers are ds_read_u8 (LDS) or global_load_ubyte; one loop
+  // with a run-time pointer select compiles to FLAT loads that wait on both counters.
+  auto rows = [&](auto srcRow) {
+    for (int q = tid; q < qw * nrows; q += 256) {
+      const int ry = (int)__umulhi((uint32_t)q, mq), dx0 = (q - ry * qw) * 4, dy = dy0 + ry;
+      const int2 yt = P.ytab[G.ytabBase + dy];
+      const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
+      const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+      const auto S0 = srcRow(sy0), S1 = srcRow(sy1);
+      uint32_t packed = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int dx = dx0 + j;
-      if (dx < G.w) {
-        const int2 xt = sX[dx];
-        const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
-        const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
-        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
-        packed |= (uint32_t)v << (8 * j);
+      for (int j = 0; j < 4; j++) {
+        const int dx = dx0 + j;
+        if (dx < G.w) {
+          const int2 xt = sX[dx];
+          const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+          const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+          const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+          const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+          int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+          v = min(max(v, 0), 255);
+          packed |= (uint32_t)v << (8 * j);
+        }
       }
+      uint8_t *dst = dstplane + (size_t)dy * G.pitch;
+      if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
+      else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
     }
-    uint8_t *dst = dstplane + (size_t)dy * G.pitch;
-    if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
-    else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
-  }
+  };
+  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + (size_t)(sy - syFirst) * smemRowBytes; });
+  else rows([&](int sy) { return src + (size_t)sy * spitch; });  // extreme scale factors: straight from global
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ struct MatchProblemSet {
   float nnratio; int th_dist; int use_second;
   // in/out
   int32_t *slot; uint8_t *slot_obs; int32_t *match_of_query; int32_t *best_dist; int32_t *nmatches;
+  long long *dbg;  // diagnostic builds (-DRESOLVE_STAMPS) only: per-problem cycle sums; never read by the product
 };
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
@@ -277,8 +278,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
   CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
   uint32_t *rest = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
-  volatile uint32_t *sClaim = rest;
-  volatile int32_t *sSlot = reinterpret_cast<volatile int32_t *>(rest + cwords);
+  // plain (non-volatile) LDS pointers: a volatile generic pointer made the compiler fall back to FLAT stores with
+  // vmcnt(0) waits (~1500 cycles per turn).  Ordering: LDS is in-order within a wave; waves meet only at barriers.
+  uint32_t *sClaim = rest;
+  int32_t *sSlot = reinterpret_cast<int32_t *>(rest + cwords);
   for (int b0 = wid * 64; b0 < n; b0 += 64 * RESOLVE_NW) {
     const int i = b0 + lane;
     const bool cl = i < n && slot[i] >= 0 && slot_obs[i];
@@ -349,6 +352,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     if (lane == 0) { sPart[wid][0] = m1; sPart[wid][1] = m2; }
   };
 
+#ifdef RESOLVE_STAMPS
+  long long t_setup = 0, t_turn = 0, t_rescan = 0, n_rescan = 0, t_chunk = 0;
+  long long t0 = __builtin_readcyclecounter();
+#endif
   if (wid != 0) {
     // helper waves: sleep at the barrier until wave 0 posts a command
     for (;;) {
@@ -359,8 +366,14 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       __syncthreads();                 // (B) partials posted
     }
   } else {
+#ifdef RESOLVE_STAMPS
+    t_setup = __builtin_readcyclecounter() - t0;
+#endif
     int nmatches = 0;
     for (int base = 0; base < nq; base += 64) {
+#ifdef RESOLVE_STAMPS
+      long long tc0 = __builtin_readcyclecounter();
+#endif
       const int q = base + lane;
       K tk[MATCH_TOPK];
       int eidx[MATCH_TOPK];       // keypoint index of entry j, -1 for an empty entry
@@ -381,13 +394,23 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       uint32_t D = decide<KT>(M, tk, cm, oct4, &my_bd);
       int res_idx = -1, res_bd = 256;
       const int cnt = min(64, nq - base);
+#ifdef RESOLVE_STAMPS
+      t_chunk += __builtin_readcyclecounter() - tc0;
+#endif
       for (int i = 0; i < cnt; i++) {
+#ifdef RESOLVE_STAMPS
+        long long tt0 = __builtin_readcyclecounter();
+        bool did_rescan = false;
+#endif
         const uint32_t Di = (uint32_t)__builtin_amdgcn_readlane((int)D, i);
         const uint32_t ob = ((uint32_t)__builtin_amdgcn_readlane((int)myfl, i) >> 1) & 1u;
         bool accept = (Di >> 31) & 1u;
         int bestIdx = (int)(Di & 0xfffff);
         if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
         if ((Di >> 30) & 1u) {
+#ifdef RESOLVE_STAMPS
+          did_rescan = true;
+#endif
           if (lane == 0) sCmd = base + i;
           __syncthreads();             // (A)
           rescan_part(base + i);
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         if (accept) {
           nmatches++;
           if (lane == 0) {
-            if (ob) sClaim[bestIdx >> 5] = sClaim[bestIdx >> 5] | (1u << (bestIdx & 31));
+            if (ob) __hip_atomic_fetch_or(&sClaim[bestIdx >> 5], 1u << (bestIdx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_or_b32, no read-wait
             sSlot[bestIdx] = (int32_t)((uint32_t)(base + i) | (ob << 30));
           }
           if (ob) {  // lanes whose list contains the claimed keypoint re-decide
@@ -421,12 +444,18 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
             if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
           }
         }
+#ifdef RESOLVE_STAMPS
+        { long long dt = __builtin_readcyclecounter() - tt0; if (did_rescan) { t_rescan += dt; n_rescan++; } else t_turn += dt; }
+#endif
       }
       if (q < nq) {
         if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
         if (M.best_dist) M.best_dist[qo + q] = res_bd;
       }
     }
+#ifdef RESOLVE_STAMPS
+    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = t_setup; d[1] = t_chunk; d[2] = t_turn; d[3] = t_rescan; d[4] = n_rescan; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; }
+#endif
     if (lane == 0) { sCmd = -1; if (M.nmatches) M.nmatches[p] = nmatches; }
     __syncthreads();                   // (A) exit command
   }

@@ -572,6 +572,10 @@ struct orbm_handle {
     }                                                                                         \
   } while (0)
 
+#ifdef RESOLVE_STAMPS
+static void *getenv_ptr(const char *name) { const char *e = getenv(name); return e ? (void *)strtoull(e, nullptr, 0) : nullptr; }
+#endif
+
 extern "C" {
 
 orbm_t *orbm_create(int device) {
@@ -732,6 +736,9 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
+#ifdef RESOLVE_STAMPS
+  M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
+#endif
   const int maxn = d_frame_n ? frame_stride : f->n;
   const int maxq = d_query_n ? query_stride : q->nq;
   if (maxn > 32768) { m->err = "more than 32768 keypoints per frame not supported by the search kernels"; return ORBX_E_ARG; }
