@@ -216,29 +216,53 @@ __device__ __forceinline__ bool accept_rule(const MatchProblemSet &M, bool has1,
   return true;
 }
 
-// Per-lane decision from a query's sorted candidate list, the "entry is claimed" mask and the entries' octaves
-// (4 bits each).  Returns accept<<31 | rescan<<30 | bestIdx; *bd_out = distance of the best surviving entry.
+// ---- wave-wide minimum through DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31); the result is uniform ---------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_or_ones(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_key(uint32_t v) {
+  uint32_t t;
+  t = dpp_or_ones<0x111, 0xf>(v); v = t < v ? t : v;
+  t = dpp_or_ones<0x112, 0xf>(v); v = t < v ? t : v;
+  t = dpp_or_ones<0x114, 0xf>(v); v = t < v ? t : v;
+  t = dpp_or_ones<0x118, 0xf>(v); v = t < v ? t : v;
+  t = dpp_or_ones<0x142, 0xa>(v); v = t < v ? t : v;
+  t = dpp_or_ones<0x143, 0xc>(v); v = t < v ? t : v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v) {
+#define ORB_DPP64_STEP(CTRL, RM)                                                                           \
+  {                                                                                                        \
+    const uint32_t lo = dpp_or_ones<CTRL, RM>((uint32_t)v), hi = dpp_or_ones<CTRL, RM>((uint32_t)(v >> 32)); \
+    const unsigned long long t = ((unsigned long long)hi << 32) | lo;                                      \
+    v = t < v ? t : v;                                                                                     \
+  }
+  ORB_DPP64_STEP(0x111, 0xf) ORB_DPP64_STEP(0x112, 0xf) ORB_DPP64_STEP(0x114, 0xf) ORB_DPP64_STEP(0x118, 0xf)
+  ORB_DPP64_STEP(0x142, 0xa) ORB_DPP64_STEP(0x143, 0xc)
+#undef ORB_DPP64_STEP
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Per-lane decision from a query's sorted candidate list (column `lane` of sTk, entry j at sTkLane[64*j]).
+//   vm   bit j: entry j exists;  cm  bit j: entry j is claimed by an earlier query;  oct4: 4-bit octave per entry.
+// Returns accept<<31 | rescan<<30 | bestIdx; *bd_out = distance of the best surviving entry (256 if none).
 //
-// Every candidate that is not in the list has key >= tk[TOPK-1], i.e. distance >= lbDist.  A rescan is needed only
-// when an unlisted candidate could change the decision:
+// Every candidate that is not in the list has key >= tk[TOPK-1], i.e. distance >= lbDist.  An exact rescan is needed
+// only when an unlisted candidate could change the decision:
 //   no survivor          and an unlisted one could be within th_dist;
 //   one survivor (best)  and the unknown second-best could make the ratio test fail (ORBmatcher.cc:126).
 template <typename KT>
-__device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typename KT::T (&tk)[MATCH_TOPK], uint32_t cm, uint32_t oct4, int *bd_out) {
+__device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typename KT::T *sTkLane, uint32_t vm, uint32_t cm,
+                                           uint32_t oct4, bool truncated, int lbDist, int *bd_out) {
   typedef typename KT::T K;
-  K best = KT::NONE, second = KT::NONE;
-  int found = 0, l1 = 0, l2 = 0;
-#pragma unroll
-  for (int j = 0; j < MATCH_TOPK; j++) {
-    const bool av = tk[j] != KT::NONE && !((cm >> j) & 1u);
-    const int lv = (int)((oct4 >> (4 * j)) & 0xfu);
-    const bool s2 = av && found == 1, s1 = av && found == 0;
-    second = s2 ? tk[j] : second; l2 = s2 ? lv : l2;
-    best = s1 ? tk[j] : best; l1 = s1 ? lv : l1;
-    found += av ? 1 : 0;
-  }
-  const bool truncated = tk[MATCH_TOPK - 1] != KT::NONE;
-  const int lbDist = KT::dist(tk[MATCH_TOPK - 1]);
+  const uint32_t av = vm & ~cm, av2 = av & (av - 1u);
+  const int found = __popc(av);
+  const int j1 = (__ffs((int)av) - 1) & (MATCH_TOPK - 1), j2 = (__ffs((int)av2) - 1) & (MATCH_TOPK - 1);
+  const K best = sTkLane[64 * j1], second = sTkLane[64 * j2];
+  const int l1 = (int)((oct4 >> (4 * j1)) & 0xfu), l2 = (int)((oct4 >> (4 * j2)) & 0xfu);
   const int bd = found > 0 ? KT::dist(best) : 256;
   bool rescan = false;
   if (truncated) {
@@ -250,20 +274,34 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
   return (acc ? 0x80000000u : 0u) | (rescan ? 0x40000000u : 0u) | (found > 0 ? (uint32_t)KT::idx(best) : 0u);
 }
 
-// One workgroup (RESOLVE_NW wavefronts) per problem, queries in order.
-// Wave 0 runs the sequential turn loop alone: each lane owns one query of the current 64-query chunk and keeps its
-// decision current; a turn = one readlane of lane i's decision, the claim, and a re-decide in the lanes whose lists
-// contain the claimed keypoint.  The other waves sleep in s_barrier and are woken only for a rescan, where all waves
-// split the keypoints and exchange their partial (best, second) through LDS (command word: query index, or -1 = exit).
-// LDS: sClaim = one bit per keypoint ("held by a map point with observations"; bits only go 0 -> 1),
-//      sSlot  = the new holder of each keypoint (query | obs<<30, or -1).
-// LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that rescans never leave the CU.
+// One workgroup per problem.  All wavefronts build the LDS state; wavefront 0 then resolves the queries, 64 at a time.
+//
+// The reference's loop is sequential only through the claims: the decision of query i is a function f_i of the claims
+// made by queries < i.  Within a chunk of 64 queries (one per lane) the decisions D_0..D_63 are therefore the unique
+// solution of D_i = f_i(D_0..D_i-1), and that solution is reached by iterating all lanes in parallel:
+//   round:  every lane that currently accepts (and whose map point has observations) posts its claim into sOwner with
+//           ds_min(lane+1); every lane reads the owner words of its TOPK entries - "claimed for me" means owner <= lane,
+//           i.e. committed (0) or posted by an EARLIER lane; the posts are withdrawn; every lane re-decides.
+// After round t the first t pending lanes are final, and a round in which no lane of a prefix changed proves that
+// prefix final.  Conflicts are sparse, so a prefix settles in two or three rounds instead of one turn per query.
+// A lane whose list is exhausted ("rescan") cuts the prefix: everything before it is committed, then the whole
+// wavefront rescans that one query exactly - only over the keypoints of the grid columns its window touches (sPerm is
+// the keypoint list sorted by grid column, sCol the column starts) - commits it, and the rounds resume behind it.
+//
+// LDS: sOwner[k] = 0 claimed (committed, or held by a map point with observations on entry), 1..64 posted by lane-1
+//                  during a round, 0xffffffff free; word n is a dummy that stays free (target of empty list entries).
+//      sSlot[k]  = max over accepted queries of (query<<1 | obs), i.e. the LAST query that took keypoint k; -1 none.
+//      LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that rescans never leave the CU.
+#define RESOLVE_FREE 0xffffffffu
+#define RESOLVE_WIDE 192  // rescans over more keypoints than this are split over all wavefronts
 template <typename KT, bool LDSCAND>
 __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
+  __shared__ K sTk[MATCH_TOPK * 64];
+  __shared__ int sCol[66 + 66];  // column starts (65 bins + end), then the scatter cursors
+  __shared__ uint32_t sCmd[20];  // rescan command for the helper waves: [0] first pos (or -1 = exit), [1] end, [2..8] window, [9..16] descriptor
   __shared__ K sPart[RESOLVE_NW][2];
-  __shared__ int sCmd;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -273,180 +311,280 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
   int32_t *slot = M.slot + fo;
   uint8_t *slot_obs = M.slot_obs + fo;
-  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [claim bitmap][slot]
-  const int cwords = ((maxn + 63) >> 6) * 2 + 2;
+  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [owner maxn+1][slot maxn][perm: maxn u16]
   uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
   CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
-  uint32_t *rest = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
-  // plain (non-volatile) LDS pointers: a volatile generic pointer made the compiler fall back to FLAT stores with
-  // vmcnt(0) waits (~1500 cycles per turn).  Ordering: LDS is in-order within a wave; waves meet only at barriers.
-  uint32_t *sClaim = rest;
-  int32_t *sSlot = reinterpret_cast<int32_t *>(rest + cwords);
-  for (int b0 = wid * 64; b0 < n; b0 += 64 * RESOLVE_NW) {
-    const int i = b0 + lane;
-    const bool cl = i < n && slot[i] >= 0 && slot_obs[i];
-    const unsigned long long mask = __ballot(cl);
-    if (lane == 0) { sClaim[(b0 >> 5)] = (uint32_t)mask; sClaim[(b0 >> 5) + 1] = (uint32_t)(mask >> 32); }
+  uint32_t *sOwner = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
+  int32_t *sSlot = reinterpret_cast<int32_t *>(sOwner + maxn + 1);
+  uint16_t *sPerm = reinterpret_cast<uint16_t *>(sSlot + maxn);
+  int *sFill = sCol + 66;
+  for (int i = tid; i < 132; i += 64 * RESOLVE_NW) sCol[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+    sOwner[i] = (slot[i] >= 0 && slot_obs[i]) ? 0u : RESOLVE_FREE;
+    sSlot[i] = -1;
+    const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
+    const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
+    if (LDSCAND) {
+      CandMeta c;
+      c.x = x; c.y = y; c.bits = bits;
+      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
+      sMeta[i] = c;
+    }
+    atomicAdd(&sCol[((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) + 1 : 65], 1);  // histogram shifted by one
   }
-  for (int i = tid; i < n; i += 64 * RESOLVE_NW) sSlot[i] = -1;
+  if (tid == 0) sOwner[n] = RESOLVE_FREE;
   if (LDSCAND) {
     const uint4 *gd = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
     for (int i = tid; i < 2 * n; i += 64 * RESOLVE_NW) sDesc[i] = gd[i];
-    for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
-      CandMeta c;
-      c.x = kp[(size_t)i * 7];
-      c.y = kp[(size_t)i * 7 + 1];
-      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
-      c.bits = cand_bits(c.x, c.y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
-      sMeta[i] = c;
-    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // exclusive prefix: sCol[c] = first position of column c, sCol[64] = end of the in-grid keypoints
+    int acc = 0;
+    for (int c = 1; c <= 65; c++) { acc += sCol[c]; sCol[c] = acc; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+    uint32_t bits;
+    if (LDSCAND) bits = sMeta[i].bits;
+    else bits = cand_bits(kp[(size_t)i * 7], kp[(size_t)i * 7 + 1], __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
+    const int col = ((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) : 64;
+    const int pos = sCol[col] + atomicAdd(&sFill[col], 1);
+    sPerm[pos] = (uint16_t)i;
   }
   __syncthreads();
   auto octave_of = [&](int idx) -> int {
     if (LDSCAND) return (int)(sMeta[idx].bits & 0xff);
     return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
   };
-  // this wave's share of an exact rescan of query qq with the current claims -> sPart[wid]
-  auto rescan_part = [&](int qq) {
-    const QueryWin w = load_query(M, qo, qq);
-    const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + qq) * 32);
-    K b1 = KT::NONE, b2 = KT::NONE;
-    if (w.live) {
-      uint32_t q8[8];
+  // exact (best, second) of one query over positions first, first+stride, ... < end of the column-sorted list, with
+  // the claims committed so far
+  auto scan_range = [&](const QueryWin &w, const uint32_t (&q8)[8], int first, int end, int stride, K &b1, K &b2) {
+    b1 = KT::NONE; b2 = KT::NONE;
+    for (int pos = first; pos < end; pos += stride) {
+      const int c = sPerm[pos];
+      const bool cl = sOwner[c] == 0u;
+      float x, y, cur;
+      uint32_t bits, d8[8];
+      if (LDSCAND) {
+        const CandMeta cmeta = sMeta[c];
+        x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
+        bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
+        const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+        d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
+      } else {
+        x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
+        bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
+        cur = M.u_right ? M.u_right[fo + c] : -1.f;
 #pragma unroll
-      for (int t = 0; t < 8; t++) q8[t] = qd[t];
-      for (int c = tid; c < n; c += 64 * RESOLVE_NW) {
-        const bool cl = (sClaim[c >> 5] >> (c & 31)) & 1u;
-        float x, y, cur;
-        uint32_t bits, d8[8];
-        if (LDSCAND) {
-          const CandMeta cmeta = sMeta[c];
-          x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
-          bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
-          const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-          d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
-        } else {
-          x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
-          bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
-          cur = M.u_right ? M.u_right[fo + c] : -1.f;
+        for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
+      }
+      if (cand_passes(w, x, y, bits, cur)) {
+        int dist = 0;
 #pragma unroll
-          for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
-        }
-        if (cand_passes(w, x, y, bits, cur)) {
-          int dist = 0;
-#pragma unroll
-          for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
-          const K key = KT::make(dist, cell_of(bits), c);
-          if (key < b1) { b2 = b1; b1 = key; }
-          else if (key < b2) b2 = key;
-        }
+        for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
+        const K key = KT::make(dist, cell_of(bits), c);
+        if (key < b1) { b2 = b1; b1 = key; }
+        else if (key < b2) b2 = key;
       }
     }
-    // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
-    K m1 = b1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m1, o); m1 = t < m1 ? t : m1; }
-    K m2 = (b1 == m1) ? b2 : b1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const K t = KT::shfl_xor(m2, o); m2 = t < m2 ? t : m2; }
-    if (lane == 0) { sPart[wid][0] = m1; sPart[wid][1] = m2; }
   };
-
-#ifdef RESOLVE_STAMPS
-  long long t_setup = 0, t_turn = 0, t_rescan = 0, n_rescan = 0, t_chunk = 0;
-  long long t0 = __builtin_readcyclecounter();
-#endif
+  auto make_window = [&](float u, float v, float r, float ur, int minl, int maxl, bool live) {
+    QueryWin w;
+    w.u = u; w.v = v; w.r = r; w.ur = ur; w.minl = minl; w.maxl = maxl;
+    w.cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w));   // Frame::GetFeaturesInArea, Frame.cc:755-777
+    w.cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
+    w.cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h));
+    w.cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
+    w.live = live && w.cx0 < 64 && w.cx1 >= 0 && w.cy0 < 48 && w.cy1 >= 0 && w.cx0 <= w.cx1;
+    w.checkLevels = (minl > 0) || (maxl >= 0);
+    w.stereo = M.u_right != nullptr;
+    return w;
+  };
   if (wid != 0) {
-    // helper waves: sleep at the barrier until wave 0 posts a command
+    // helper waves: sleep at the barrier until wave 0 posts a wide rescan (or the exit command)
     for (;;) {
       __syncthreads();                 // (A) command posted
-      const int cmd = sCmd;
-      if (cmd < 0) break;
-      rescan_part(cmd);
+      const int first = (int)sCmd[0];
+      if (first < 0) break;
+      const QueryWin w = make_window(__uint_as_float(sCmd[2]), __uint_as_float(sCmd[3]), __uint_as_float(sCmd[4]), __uint_as_float(sCmd[5]),
+                                     (int)sCmd[6], (int)sCmd[7], true);
+      uint32_t q8[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) q8[t] = sCmd[9 + t];
+      K b1, b2;
+      scan_range(w, q8, first + tid, (int)sCmd[1], 64 * RESOLVE_NW, b1, b2);
+      const K m1 = wave_min_key(b1);
+      const K m2 = wave_min_key((b1 == m1) ? b2 : b1);
+      if (lane == 0) { sPart[wid][0] = m1; sPart[wid][1] = m2; }
       __syncthreads();                 // (B) partials posted
     }
-  } else {
+  }
 #ifdef RESOLVE_STAMPS
-    t_setup = __builtin_readcyclecounter() - t0;
+  long long t_setup = 0, t_round = 0, t_rescan = 0, n_rescan = 0, t_chunk = 0, n_round = 0;
+  long long t0 = __builtin_readcyclecounter();
 #endif
+  if (wid == 0) {
     int nmatches = 0;
     for (int base = 0; base < nq; base += 64) {
 #ifdef RESOLVE_STAMPS
       long long tc0 = __builtin_readcyclecounter();
 #endif
       const int q = base + lane;
-      K tk[MATCH_TOPK];
-      int eidx[MATCH_TOPK];       // keypoint index of entry j, -1 for an empty entry
-      uint32_t cm = 0, oct4 = 0;  // bit j: entry j of my list is claimed; 4 bits per entry: its octave
+      const int cnt = min(64, nq - base);
+      // my query: list, parameters and descriptor (registers; broadcast by readlane when my query is rescanned)
+      int eidx[MATCH_TOPK];       // keypoint index of entry j, n (the dummy) for an empty entry
+      uint32_t vm = 0, oct4 = 0;
+      K last = KT::NONE;
 #pragma unroll
       for (int j = 0; j < MATCH_TOPK; j++) {
-        tk[j] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
-        eidx[j] = -1;
-        if (tk[j] != KT::NONE) {
-          const int idx = KT::idx(tk[j]);
+        const K t = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+        sTk[64 * j + lane] = t;
+        eidx[j] = n;
+        if (t != KT::NONE) {
+          const int idx = KT::idx(t);
           eidx[j] = idx;
-          cm |= ((sClaim[idx >> 5] >> (idx & 31)) & 1u) << j;
+          vm |= 1u << j;
           oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
         }
+        last = t;
       }
+      const bool truncated = last != KT::NONE;
+      const int lbDist = KT::dist(last);
       const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
-      int my_bd;
-      uint32_t D = decide<KT>(M, tk, cm, oct4, &my_bd);
-      int res_idx = -1, res_bd = 256;
-      const int cnt = min(64, nq - base);
+      const bool ob = (myfl >> 1) & 1u;
+      float qu = 0.f, qv = 0.f, qr = 0.f, qur = 0.f;
+      int qminl = 0, qmaxl = 0;
+      uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < nq) {
+        qu = M.qu[qo + q]; qv = M.qv[qo + q]; qr = M.qr[qo + q];
+        qminl = M.qminl[qo + q]; qmaxl = M.qmaxl[qo + q];
+        qur = M.qur ? M.qur[qo + q] : 0.f;
+        const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
+        const uint4 a = qp[0], b = qp[1];
+        qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+      }
+      uint32_t D = 0;
+      int my_bd = 256, res_idx = -1, res_bd = 256;
 #ifdef RESOLVE_STAMPS
       t_chunk += __builtin_readcyclecounter() - tc0;
 #endif
-      for (int i = 0; i < cnt; i++) {
+      int s = 0;
+      while (s < cnt) {
 #ifdef RESOLVE_STAMPS
-        long long tt0 = __builtin_readcyclecounter();
-        bool did_rescan = false;
+        long long tr0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t Di = (uint32_t)__builtin_amdgcn_readlane((int)D, i);
-        const uint32_t ob = ((uint32_t)__builtin_amdgcn_readlane((int)myfl, i) >> 1) & 1u;
-        bool accept = (Di >> 31) & 1u;
-        int bestIdx = (int)(Di & 0xfffff);
-        if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
-        if ((Di >> 30) & 1u) {
-#ifdef RESOLVE_STAMPS
-          did_rescan = true;
-#endif
-          if (lane == 0) sCmd = base + i;
-          __syncthreads();             // (A)
-          rescan_part(base + i);
-          __syncthreads();             // (B)
-          K g1 = KT::NONE, g2 = KT::NONE;
+        int r;
+        for (;;) {
+          const bool pend = lane >= s && lane < cnt;
+          const bool post = pend && (D >> 31) && ob;
+          const int bidx = (int)(D & 0xfffffu);
+          if (post) __hip_atomic_fetch_min(&sOwner[bidx], (uint32_t)(lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __builtin_amdgcn_wave_barrier();
+          uint32_t cm = 0;
 #pragma unroll
-          for (int ww = 0; ww < RESOLVE_NW; ww++) {
-            const K a1 = sPart[ww][0], a2 = sPart[ww][1];
-            const K nb = g1 < a1 ? g1 : a1;
-            const K mx = g1 < a1 ? a1 : g1;
-            const K ms = g2 < a2 ? g2 : a2;
-            g2 = mx < ms ? mx : ms;
-            g1 = nb;
+          for (int j = 0; j < MATCH_TOPK; j++) cm |= (sOwner[eidx[j]] <= (uint32_t)lane ? 1u : 0u) << j;
+          // withdraw the post - unless the keypoint was committed since my (stale) decision was taken, e.g. by the
+          // query that has just been rescanned: a committed claim (0) must survive
+          const uint32_t mine = sOwner[post ? bidx : n];
+          __builtin_amdgcn_wave_barrier();
+          if (post && mine != 0u) sOwner[bidx] = RESOLVE_FREE;
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t nD = pend ? decide<KT>(M, sTk + lane, vm, cm, oct4, truncated, lbDist, &my_bd) : D;
+          const bool changed = nD != D;
+          D = nD;
+          const unsigned long long rm = __ballot(pend && ((D >> 30) & 1u));
+          r = rm ? (int)__builtin_ctzll(rm) : cnt;
+          const unsigned long long chg = __ballot(changed && lane <= r);
+#ifdef RESOLVE_STAMPS
+          n_round++;
+#endif
+          if (!chg) break;
+        }
+        // commit the settled prefix [s, r)
+        {
+          const bool inpre = lane >= s && lane < r;
+          const bool acc = inpre && (D >> 31);
+          const int bidx = (int)(D & 0xfffffu);
+          nmatches += __popcll(__ballot(acc));
+          if (acc) {
+            if (ob) sOwner[bidx] = 0u;
+            __hip_atomic_fetch_max(&sSlot[bidx], (int32_t)(((uint32_t)q << 1) | (ob ? 1u : 0u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (inpre) { res_idx = acc ? bidx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef RESOLVE_STAMPS
+        t_round += __builtin_readcyclecounter() - tr0;
+#endif
+        if (r < cnt) {
+#ifdef RESOLVE_STAMPS
+          long long ts0 = __builtin_readcyclecounter();
+#endif
+          // exact rescan of query base+r with the claims committed so far: this wavefront alone when the window
+          // touches few keypoints, all wavefronts of the workgroup otherwise
+          const uint32_t rfl = (uint32_t)__builtin_amdgcn_readlane((int)myfl, r);
+          const QueryWin w = make_window(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qu), r)),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), r)),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qr), r)),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qur), r)),
+                                         __builtin_amdgcn_readlane(qminl, r), __builtin_amdgcn_readlane(qmaxl, r), (rfl & 1u) != 0);
+          uint32_t q8[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) q8[t] = (uint32_t)__builtin_amdgcn_readlane((int)qd[t], r);
+          const int first = w.live ? sCol[w.cx0] : 0, end = w.live ? sCol[w.cx1 + 1] : 0;
+          K g1, g2;
+          if (end - first > RESOLVE_WIDE) {
+            if (lane == 0) {
+              sCmd[0] = (uint32_t)first; sCmd[1] = (uint32_t)end;
+              sCmd[2] = __float_as_uint(w.u); sCmd[3] = __float_as_uint(w.v); sCmd[4] = __float_as_uint(w.r); sCmd[5] = __float_as_uint(w.ur);
+              sCmd[6] = (uint32_t)w.minl; sCmd[7] = (uint32_t)w.maxl;
+#pragma unroll
+              for (int t = 0; t < 8; t++) sCmd[9 + t] = q8[t];
+            }
+            __syncthreads();           // (A)
+            K b1, b2;
+            scan_range(w, q8, first + tid, end, 64 * RESOLVE_NW, b1, b2);
+            const K m1 = wave_min_key(b1);
+            const K m2 = wave_min_key((b1 == m1) ? b2 : b1);
+            if (lane == 0) { sPart[0][0] = m1; sPart[0][1] = m2; }
+            __syncthreads();           // (B)
+            g1 = KT::NONE; g2 = KT::NONE;
+#pragma unroll
+            for (int ww = 0; ww < RESOLVE_NW; ww++) {
+              const K a1 = sPart[ww][0], a2 = sPart[ww][1];
+              const K nb = g1 < a1 ? g1 : a1;
+              const K mx = g1 < a1 ? a1 : g1;
+              const K ms = g2 < a2 ? g2 : a2;
+              g2 = mx < ms ? mx : ms;
+              g1 = nb;
+            }
+          } else {
+            K b1, b2;
+            scan_range(w, q8, first + lane, end, 64, b1, b2);
+            // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
+            g1 = wave_min_key(b1);
+            g2 = wave_min_key((b1 == g1) ? b2 : b1);
           }
           const bool has1 = g1 != KT::NONE, has2 = g2 != KT::NONE;
           const int bd = has1 ? KT::dist(g1) : 256;
-          bestIdx = has1 ? KT::idx(g1) : 0;
-          accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
-          if (lane == i) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; }
-        }
-        if (accept) {
-          nmatches++;
-          if (lane == 0) {
-            if (ob) __hip_atomic_fetch_or(&sClaim[bestIdx >> 5], 1u << (bestIdx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_or_b32, no read-wait
-            sSlot[bestIdx] = (int32_t)((uint32_t)(base + i) | (ob << 30));
+          const int bestIdx = has1 ? KT::idx(g1) : 0;
+          const bool accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
+          const uint32_t rob = (rfl >> 1) & 1u;
+          if (accept) {
+            nmatches++;
+            if (lane == 0) {
+              if (rob) sOwner[bestIdx] = 0u;
+              __hip_atomic_fetch_max(&sSlot[bestIdx], (int32_t)(((uint32_t)(base + r) << 1) | rob), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
-          if (ob) {  // lanes whose list contains the claimed keypoint re-decide
-            uint32_t ncm = cm;
-#pragma unroll
-            for (int j = 0; j < MATCH_TOPK; j++) ncm |= (eidx[j] == bestIdx ? 1u : 0u) << j;
-            if (ncm != cm) { cm = ncm; D = decide<KT>(M, tk, cm, oct4, &my_bd); }
-          }
-        }
+          if (lane == r) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; D = 0; }
+          __builtin_amdgcn_wave_barrier();
 #ifdef RESOLVE_STAMPS
-        { long long dt = __builtin_readcyclecounter() - tt0; if (did_rescan) { t_rescan += dt; n_rescan++; } else t_turn += dt; }
+          t_rescan += __builtin_readcyclecounter() - ts0; n_rescan++;
 #endif
+        }
+        s = r + 1;
       }
       if (q < nq) {
         if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
@@ -454,15 +592,15 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       }
     }
 #ifdef RESOLVE_STAMPS
-    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = t_setup; d[1] = t_chunk; d[2] = t_turn; d[3] = t_rescan; d[4] = n_rescan; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; }
+    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = t_setup; d[1] = t_chunk; d[2] = t_round; d[3] = t_rescan; d[4] = n_rescan; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; d[7] = n_round; }
 #endif
-    if (lane == 0) { sCmd = -1; if (M.nmatches) M.nmatches[p] = nmatches; }
+    if (lane == 0) { sCmd[0] = 0xffffffffu; if (M.nmatches) M.nmatches[p] = nmatches; }
     __syncthreads();                   // (A) exit command
   }
   __syncthreads();                     // sSlot complete
   for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
     const int32_t v = sSlot[i];
-    if (v >= 0) { slot[i] = v & 0x3fffffff; slot_obs[i] = (uint8_t)((v >> 30) & 1); }
+    if (v >= 0) { slot[i] = v >> 1; slot_obs[i] = (uint8_t)(v & 1); }
   }
 }
 

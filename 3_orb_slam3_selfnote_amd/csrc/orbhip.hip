@@ -741,7 +741,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
 #endif
   const int maxn = d_frame_n ? frame_stride : f->n;
   const int maxq = d_query_n ? query_stride : q->nq;
-  if (maxn > 32768) { m->err = "more than 32768 keypoints per frame not supported by the search kernels"; return ORBX_E_ARG; }
+  if (maxn > ORBM_MAX_KEYPOINTS) { m->err = "more than 15360 keypoints per frame not supported by the search kernels"; return ORBX_E_ARG; }
   if (maxn <= 0 || maxq <= 0) return ORBX_E_ARG;
   // scratch: TOPK keys per query (grows on demand; not on the steady-state path)
   const bool k32 = maxn <= 2048;  // Key32 holds an 11-bit keypoint index
@@ -754,7 +754,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   m->ms_valid = false;
   if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
-  const size_t small = sizeof(uint32_t) * (size_t)((((maxn + 63) / 64) * 2 + 2) + maxn + 2);
+  // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16); see k_match_resolve
+  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + 2);
   const size_t big = small + 48 * (size_t)maxn;
   const bool ldscand = big <= 150 * 1024;
   const size_t lds = ldscand ? big : small;

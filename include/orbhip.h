@@ -118,6 +118,7 @@ float orbx_ref_sinf(float x);
 #define ORBM_HISTO_LENGTH 30
 #define ORBM_GRID_COLS 64 /* Frame.h:38 */
 #define ORBM_GRID_ROWS 48 /* Frame.h:39 */
+#define ORBM_MAX_KEYPOINTS 15360 /* per frame, projection search: its claim state lives in one CU's LDS */
 
 typedef struct orbm_handle orbm_t;
 orbm_t *orbm_create(int device);
