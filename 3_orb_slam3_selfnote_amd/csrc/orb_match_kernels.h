@@ -280,28 +280,34 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 // made by queries < i.  Within a chunk of 64 queries (one per lane) the decisions D_0..D_63 are therefore the unique
 // solution of D_i = f_i(D_0..D_i-1), and that solution is reached by iterating all lanes in parallel:
 //   round:  every lane that currently accepts (and whose map point has observations) posts its claim into sOwner with
-//           ds_min(lane+1); every lane reads the owner words of its TOPK entries - "claimed for me" means owner <= lane,
+//           ds_min(lane+1); every lane reads the owner words of its list entries - "claimed for me" means owner <= lane,
 //           i.e. committed (0) or posted by an EARLIER lane; the posts are withdrawn; every lane re-decides.
 // After round t the first t pending lanes are final, and a round in which no lane of a prefix changed proves that
 // prefix final.  Conflicts are sparse, so a prefix settles in two or three rounds instead of one turn per query.
-// A lane whose list is exhausted ("rescan") cuts the prefix: everything before it is committed, then the whole
-// wavefront rescans that one query exactly - only over the keypoints of the grid columns its window touches (sPerm is
-// the keypoint list sorted by grid column, sCol the column starts) - commits it, and the rounds resume behind it.
+// A lane whose list is exhausted (decide(): an unlisted keypoint could change its decision) cuts the prefix: everything
+// before it is committed, then the lane - together with every other exhausted lane, one wavefront each, up to
+// RESOLVE_NW at a time - gets a FRESH list: the REFRESH_K best keypoints of its window that no committed claim holds,
+// found by scanning only the grid columns the window touches (sPerm = keypoints sorted by grid column, sCol = column
+// starts).  A list is valid as long as it was the head of the unclaimed candidates when it was made - later claims
+// are seen through sOwner - so refreshing is always safe, and right after it the lane is first in line and decides.
+// tests/resolve_model.py is an executable restatement, tested against the plain in-order loop.
 //
 // LDS: sOwner[k] = 0 claimed (committed, or held by a map point with observations on entry), 1..64 posted by lane-1
 //                  during a round, 0xffffffff free; word n is a dummy that stays free (target of empty list entries).
 //      sSlot[k]  = max over accepted queries of (query<<1 | obs), i.e. the LAST query that took keypoint k; -1 none.
-//      LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that rescans never leave the CU.
+//      sTk[j][lane] = entry j of lane's current list.
+//      LDSCAND: descriptors + positions staged in LDS once (48 B per keypoint) so that refreshes never leave the CU.
 #define RESOLVE_FREE 0xffffffffu
-#define RESOLVE_WIDE 192  // rescans over more keypoints than this are split over all wavefronts
+#define REFRESH_K 4
+#define REQ_WORDS 16  // lane, flags, u, v, r, ur, minl, maxl, descriptor[8]
 template <typename KT, bool LDSCAND>
 __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
   __shared__ K sTk[MATCH_TOPK * 64];
   __shared__ int sCol[66 + 66];  // column starts (65 bins + end), then the scatter cursors
-  __shared__ uint32_t sCmd[20];  // rescan command for the helper waves: [0] first pos (or -1 = exit), [1] end, [2..8] window, [9..16] descriptor
-  __shared__ K sPart[RESOLVE_NW][2];
+  __shared__ int sCmd;           // number of refresh requests posted, -1 = exit
+  __shared__ uint32_t sReq[RESOLVE_NW][REQ_WORDS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -357,74 +363,110 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     if (LDSCAND) return (int)(sMeta[idx].bits & 0xff);
     return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
   };
-  // exact (best, second) of one query over positions first, first+stride, ... < end of the column-sorted list, with
-  // the claims committed so far
-  auto scan_range = [&](const QueryWin &w, const uint32_t (&q8)[8], int first, int end, int stride, K &b1, K &b2) {
-    b1 = KT::NONE; b2 = KT::NONE;
-    for (int pos = first; pos < end; pos += stride) {
-      const int c = sPerm[pos];
-      const bool cl = sOwner[c] == 0u;
-      float x, y, cur;
-      uint32_t bits, d8[8];
+  // One wavefront serves refresh request `rq`: the REFRESH_K smallest keys of the query's window among the keypoints
+  // no committed claim holds -> column `target lane` of sTk.
+  auto serve = [&](int rq) {
+    const uint32_t *R = sReq[rq];
+    const int target = (int)R[0];
+    QueryWin w;
+    w.u = __uint_as_float(R[2]); w.v = __uint_as_float(R[3]); w.r = __uint_as_float(R[4]); w.ur = __uint_as_float(R[5]);
+    w.minl = (int)R[6]; w.maxl = (int)R[7];
+    w.cx0 = max(0, (int)floorf((w.u - M.min_x - w.r) * M.inv_w));   // Frame::GetFeaturesInArea, Frame.cc:755-777
+    w.cx1 = min(63, (int)ceilf((w.u - M.min_x + w.r) * M.inv_w));
+    w.cy0 = max(0, (int)floorf((w.v - M.min_y - w.r) * M.inv_h));
+    w.cy1 = min(47, (int)ceilf((w.v - M.min_y + w.r) * M.inv_h));
+    w.live = (R[1] & 1u) && w.cx0 < 64 && w.cx1 >= 0 && w.cy0 < 48 && w.cy1 >= 0 && w.cx0 <= w.cx1;
+    w.checkLevels = (w.minl > 0) || (w.maxl >= 0);
+    w.stereo = M.u_right != nullptr;
+    uint32_t q8[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) q8[t] = R[8 + t];
+    K l[REFRESH_K];
+#pragma unroll
+    for (int j = 0; j < REFRESH_K; j++) l[j] = KT::NONE;
+    // level filter as a closed interval (open ends when disabled), window test in sign-bit arithmetic as in k_match_scan
+    const int minlE = w.checkLevels ? w.minl : -1000, maxlE = w.checkLevels && w.maxl >= 0 ? w.maxl : 1000;
+    struct Cand { float x, y, ur; uint32_t bits, d[8]; int c; };
+    auto fetch = [&](int pos, bool valid) {
+      Cand k;
+      k.c = valid ? (int)sPerm[pos] : -1;
+      const int c = valid ? k.c : 0;
+      const bool cl = sOwner[valid ? c : n] == 0u;
       if (LDSCAND) {
         const CandMeta cmeta = sMeta[c];
-        x = cmeta.x; y = cmeta.y; cur = cmeta.ur;
-        bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
+        k.x = cmeta.x; k.y = cmeta.y; k.ur = cmeta.ur;
+        k.bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
         const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-        d8[0] = a.x; d8[1] = a.y; d8[2] = a.z; d8[3] = a.w; d8[4] = b.x; d8[5] = b.y; d8[6] = b.z; d8[7] = b.w;
+        k.d[0] = a.x; k.d[1] = a.y; k.d[2] = a.z; k.d[3] = a.w; k.d[4] = b.x; k.d[5] = b.y; k.d[6] = b.z; k.d[7] = b.w;
       } else {
-        x = kp[(size_t)c * 7]; y = kp[(size_t)c * 7 + 1];
-        bits = cand_bits(x, y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
-        cur = M.u_right ? M.u_right[fo + c] : -1.f;
+        k.x = kp[(size_t)c * 7]; k.y = kp[(size_t)c * 7 + 1];
+        k.bits = cand_bits(k.x, k.y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
+        k.ur = M.u_right ? M.u_right[fo + c] : -1.f;
 #pragma unroll
-        for (int t = 0; t < 8; t++) d8[t] = desc[(size_t)c * 8 + t];
+        for (int t = 0; t < 8; t++) k.d[t] = desc[(size_t)c * 8 + t];
       }
-      if (cand_passes(w, x, y, bits, cur)) {
+      return k;
+    };
+    auto consider = [&](const Cand &k) {
+      const int gx = (k.bits >> 8) & 0xff, gy = (k.bits >> 16) & 0xff, oct = k.bits & 0xff;
+      int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct) | k.c;
+      viol |= ~(int)(k.bits << 7);                                    // bit 24 = usable (in grid, not claimed)
+      const int fpass = __float_as_int(fabsf(k.x - w.u) - w.r) & __float_as_int(fabsf(k.y - w.v) - w.r);
+      bool ok = (fpass & ~viol) < 0;
+      if (w.stereo) ok = ok && !(k.ur > 0.f && fabsf(w.ur - k.ur) > w.r);   // ORBmatcher.cc:93-98, :2139-2146
+      if (ok) {
         int dist = 0;
 #pragma unroll
-        for (int t = 0; t < 8; t++) dist += __popc(d8[t] ^ q8[t]);
-        const K key = KT::make(dist, cell_of(bits), c);
-        if (key < b1) { b2 = b1; b1 = key; }
-        else if (key < b2) b2 = key;
+        for (int t = 0; t < 8; t++) dist += __popc(k.d[t] ^ q8[t]);
+        K t = KT::make(dist, cell_of(k.bits), k.c);
+        if (t < l[REFRESH_K - 1]) {
+#pragma unroll
+          for (int j = 0; j < REFRESH_K; j++) {
+            const K lo = t < l[j] ? t : l[j];
+            const K hi = t < l[j] ? l[j] : t;
+            l[j] = lo;
+            t = hi;
+          }
+        }
+      }
+    };
+    const int end = w.live ? sCol[w.cx1 + 1] : 0;
+    for (int pos = (w.live ? sCol[w.cx0] : 0) + lane; pos < end; pos += 128) {  // two keypoints in flight per lane
+      const Cand k0 = fetch(pos, true);
+      const Cand k1 = fetch(pos + 64, pos + 64 < end);
+      consider(k0);
+      consider(k1);
+    }
+    // REFRESH_K extractions of the wave minimum; keys are unique, so exactly one lane pops per extraction
+    K out[REFRESH_K];
+#pragma unroll
+    for (int j = 0; j < REFRESH_K; j++) {
+      out[j] = wave_min_key(l[0]);
+      if (l[0] == out[j] && out[j] != KT::NONE) {
+#pragma unroll
+        for (int t = 0; t + 1 < REFRESH_K; t++) l[t] = l[t + 1];
+        l[REFRESH_K - 1] = KT::NONE;
       }
     }
-  };
-  auto make_window = [&](float u, float v, float r, float ur, int minl, int maxl, bool live) {
-    QueryWin w;
-    w.u = u; w.v = v; w.r = r; w.ur = ur; w.minl = minl; w.maxl = maxl;
-    w.cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w));   // Frame::GetFeaturesInArea, Frame.cc:755-777
-    w.cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
-    w.cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h));
-    w.cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
-    w.live = live && w.cx0 < 64 && w.cx1 >= 0 && w.cy0 < 48 && w.cy1 >= 0 && w.cx0 <= w.cx1;
-    w.checkLevels = (minl > 0) || (maxl >= 0);
-    w.stereo = M.u_right != nullptr;
-    return w;
-  };
-  if (wid != 0) {
-    // helper waves: sleep at the barrier until wave 0 posts a wide rescan (or the exit command)
-    for (;;) {
-      __syncthreads();                 // (A) command posted
-      const int first = (int)sCmd[0];
-      if (first < 0) break;
-      const QueryWin w = make_window(__uint_as_float(sCmd[2]), __uint_as_float(sCmd[3]), __uint_as_float(sCmd[4]), __uint_as_float(sCmd[5]),
-                                     (int)sCmd[6], (int)sCmd[7], true);
-      uint32_t q8[8];
+    if (lane == 0) {
 #pragma unroll
-      for (int t = 0; t < 8; t++) q8[t] = sCmd[9 + t];
-      K b1, b2;
-      scan_range(w, q8, first + tid, (int)sCmd[1], 64 * RESOLVE_NW, b1, b2);
-      const K m1 = wave_min_key(b1);
-      const K m2 = wave_min_key((b1 == m1) ? b2 : b1);
-      if (lane == 0) { sPart[wid][0] = m1; sPart[wid][1] = m2; }
-      __syncthreads();                 // (B) partials posted
+      for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + target] = j < REFRESH_K ? out[j] : KT::NONE;
     }
-  }
+  };
 #ifdef RESOLVE_STAMPS
-  long long t_setup = 0, t_round = 0, t_rescan = 0, n_rescan = 0, t_chunk = 0, n_round = 0;
+  long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0;
   long long t0 = __builtin_readcyclecounter();
 #endif
-  if (wid == 0) {
+  if (wid != 0) {
+    // helper waves: sleep at the barrier until wave 0 posts refresh requests (or the exit command)
+    for (;;) {
+      __syncthreads();                 // (A) requests posted
+      const int m = sCmd;
+      if (m < 0) break;
+      if (wid < m) serve(wid);
+      __syncthreads();                 // (B) lists written
+    }
+  } else {
     int nmatches = 0;
     for (int base = 0; base < nq; base += 64) {
 #ifdef RESOLVE_STAMPS
@@ -432,49 +474,91 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
 #endif
       const int q = base + lane;
       const int cnt = min(64, nq - base);
-      // my query: list, parameters and descriptor (registers; broadcast by readlane when my query is rescanned)
-      int eidx[MATCH_TOPK];       // keypoint index of entry j, n (the dummy) for an empty entry
-      uint32_t vm = 0, oct4 = 0;
-      K last = KT::NONE;
-#pragma unroll
-      for (int j = 0; j < MATCH_TOPK; j++) {
-        const K t = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
-        sTk[64 * j + lane] = t;
-        eidx[j] = n;
-        if (t != KT::NONE) {
-          const int idx = KT::idx(t);
-          eidx[j] = idx;
-          vm |= 1u << j;
-          oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
-        }
-        last = t;
-      }
-      const bool truncated = last != KT::NONE;
-      const int lbDist = KT::dist(last);
+      // my query: parameters and descriptor stay in registers (they become a refresh request if my list runs out)
       const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
       const bool ob = (myfl >> 1) & 1u;
-      float qu = 0.f, qv = 0.f, qr = 0.f, qur = 0.f;
-      int qminl = 0, qmaxl = 0;
-      uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t qpar[6] = {0, 0, 0, 0, 0, 0}, qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + lane] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
       if (q < nq) {
-        qu = M.qu[qo + q]; qv = M.qv[qo + q]; qr = M.qr[qo + q];
-        qminl = M.qminl[qo + q]; qmaxl = M.qmaxl[qo + q];
-        qur = M.qur ? M.qur[qo + q] : 0.f;
+        qpar[0] = __float_as_uint(M.qu[qo + q]); qpar[1] = __float_as_uint(M.qv[qo + q]); qpar[2] = __float_as_uint(M.qr[qo + q]);
+        qpar[3] = __float_as_uint(M.qur ? M.qur[qo + q] : 0.f);
+        qpar[4] = (uint32_t)M.qminl[qo + q]; qpar[5] = (uint32_t)M.qmaxl[qo + q];
         const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
         const uint4 a = qp[0], b = qp[1];
         qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
       }
+      // my list as the rounds need it: keypoint index per entry (n = the dummy for an empty entry), validity mask,
+      // octaves, and the lower bound every unlisted candidate obeys (entry capm1, the last one the list can hold)
+      int eidx[MATCH_TOPK];
+      uint32_t vm, oct4;
+      int capm1 = MATCH_TOPK - 1, lbDist;
+      bool truncated;
+      auto load_list = [&]() {
+        vm = 0; oct4 = 0;
+#pragma unroll
+        for (int j = 0; j < MATCH_TOPK; j++) {
+          const K t = sTk[64 * j + lane];
+          eidx[j] = n;
+          if (t != KT::NONE) {
+            const int idx = KT::idx(t);
+            eidx[j] = idx;
+            vm |= 1u << j;
+            oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
+          }
+        }
+        const K last = sTk[64 * capm1 + lane];
+        truncated = last != KT::NONE;
+        lbDist = KT::dist(last);
+      };
+      load_list();
+      // refresh the lists of the lanes in F, RESOLVE_NW per pass (one wavefront each)
+      auto refresh = [&](unsigned long long F) {
+#ifdef RESOLVE_STAMPS
+        long long ts0 = __builtin_readcyclecounter();
+#endif
+        const bool mineF = (F >> lane) & 1ull;
+        unsigned long long todo = F;
+        while (todo) {
+          const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+          const bool take = ((todo >> lane) & 1ull) && rank < RESOLVE_NW;
+          if (take) {
+            uint32_t *R = sReq[rank];
+            R[0] = (uint32_t)lane; R[1] = myfl;
+#pragma unroll
+            for (int t = 0; t < 6; t++) R[2 + t] = qpar[t];
+#pragma unroll
+            for (int t = 0; t < 8; t++) R[8 + t] = qd[t];
+          }
+          const int m = min(RESOLVE_NW, (int)__popcll(todo));
+          if (lane == 0) sCmd = m;
+          __syncthreads();             // (A)
+          serve(0);
+          __syncthreads();             // (B)
+          todo &= ~__ballot(take);
+#ifdef RESOLVE_STAMPS
+          n_batch++;
+#endif
+        }
+        if (mineF) capm1 = REFRESH_K - 1;
+        load_list();
+#ifdef RESOLVE_STAMPS
+        t_refresh += __builtin_readcyclecounter() - ts0; n_refresh += __popcll(F);
+#endif
+      };
       uint32_t D = 0;
       int my_bd = 256, res_idx = -1, res_bd = 256;
 #ifdef RESOLVE_STAMPS
       t_chunk += __builtin_readcyclecounter() - tc0;
 #endif
       int s = 0;
+      bool first_round = true;
       while (s < cnt) {
 #ifdef RESOLVE_STAMPS
         long long tr0 = __builtin_readcyclecounter();
 #endif
         int r;
+        unsigned long long flagged;
         for (;;) {
           const bool pend = lane >= s && lane < cnt;
           const bool post = pend && (D >> 31) && ob;
@@ -484,8 +568,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           uint32_t cm = 0;
 #pragma unroll
           for (int j = 0; j < MATCH_TOPK; j++) cm |= (sOwner[eidx[j]] <= (uint32_t)lane ? 1u : 0u) << j;
-          // withdraw the post - unless the keypoint was committed since my (stale) decision was taken, e.g. by the
-          // query that has just been rescanned: a committed claim (0) must survive
+          // withdraw the post - unless the keypoint was committed since my (stale) decision was taken: a committed
+          // claim (0) must survive
           const uint32_t mine = sOwner[post ? bidx : n];
           __builtin_amdgcn_wave_barrier();
           if (post && mine != 0u) sOwner[bidx] = RESOLVE_FREE;
@@ -493,13 +577,25 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           const uint32_t nD = pend ? decide<KT>(M, sTk + lane, vm, cm, oct4, truncated, lbDist, &my_bd) : D;
           const bool changed = nD != D;
           D = nD;
-          const unsigned long long rm = __ballot(pend && ((D >> 30) & 1u));
-          r = rm ? (int)__builtin_ctzll(rm) : cnt;
-          const unsigned long long chg = __ballot(changed && lane <= r);
+          flagged = __ballot(pend && ((D >> 30) & 1u));
 #ifdef RESOLVE_STAMPS
           n_round++;
 #endif
-          if (!chg) break;
+          if (first_round) {
+            first_round = false;
+            if (flagged) {             // exhausted by the claims of earlier chunks: refresh them all at once
+#ifdef RESOLVE_STAMPS
+              t_round += __builtin_readcyclecounter() - tr0;
+#endif
+              refresh(flagged);
+#ifdef RESOLVE_STAMPS
+              tr0 = __builtin_readcyclecounter();
+#endif
+              continue;
+            }
+          }
+          r = flagged ? (int)__builtin_ctzll(flagged) : cnt;
+          if (!__ballot(changed && lane <= r)) break;
         }
         // commit the settled prefix [s, r)
         {
@@ -517,74 +613,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
 #ifdef RESOLVE_STAMPS
         t_round += __builtin_readcyclecounter() - tr0;
 #endif
-        if (r < cnt) {
-#ifdef RESOLVE_STAMPS
-          long long ts0 = __builtin_readcyclecounter();
-#endif
-          // exact rescan of query base+r with the claims committed so far: this wavefront alone when the window
-          // touches few keypoints, all wavefronts of the workgroup otherwise
-          const uint32_t rfl = (uint32_t)__builtin_amdgcn_readlane((int)myfl, r);
-          const QueryWin w = make_window(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qu), r)),
-                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), r)),
-                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qr), r)),
-                                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qur), r)),
-                                         __builtin_amdgcn_readlane(qminl, r), __builtin_amdgcn_readlane(qmaxl, r), (rfl & 1u) != 0);
-          uint32_t q8[8];
-#pragma unroll
-          for (int t = 0; t < 8; t++) q8[t] = (uint32_t)__builtin_amdgcn_readlane((int)qd[t], r);
-          const int first = w.live ? sCol[w.cx0] : 0, end = w.live ? sCol[w.cx1 + 1] : 0;
-          K g1, g2;
-          if (end - first > RESOLVE_WIDE) {
-            if (lane == 0) {
-              sCmd[0] = (uint32_t)first; sCmd[1] = (uint32_t)end;
-              sCmd[2] = __float_as_uint(w.u); sCmd[3] = __float_as_uint(w.v); sCmd[4] = __float_as_uint(w.r); sCmd[5] = __float_as_uint(w.ur);
-              sCmd[6] = (uint32_t)w.minl; sCmd[7] = (uint32_t)w.maxl;
-#pragma unroll
-              for (int t = 0; t < 8; t++) sCmd[9 + t] = q8[t];
-            }
-            __syncthreads();           // (A)
-            K b1, b2;
-            scan_range(w, q8, first + tid, end, 64 * RESOLVE_NW, b1, b2);
-            const K m1 = wave_min_key(b1);
-            const K m2 = wave_min_key((b1 == m1) ? b2 : b1);
-            if (lane == 0) { sPart[0][0] = m1; sPart[0][1] = m2; }
-            __syncthreads();           // (B)
-            g1 = KT::NONE; g2 = KT::NONE;
-#pragma unroll
-            for (int ww = 0; ww < RESOLVE_NW; ww++) {
-              const K a1 = sPart[ww][0], a2 = sPart[ww][1];
-              const K nb = g1 < a1 ? g1 : a1;
-              const K mx = g1 < a1 ? a1 : g1;
-              const K ms = g2 < a2 ? g2 : a2;
-              g2 = mx < ms ? mx : ms;
-              g1 = nb;
-            }
-          } else {
-            K b1, b2;
-            scan_range(w, q8, first + lane, end, 64, b1, b2);
-            // wave top-2: min of the bests, then min over (loser's best | winner's second); keys are unique
-            g1 = wave_min_key(b1);
-            g2 = wave_min_key((b1 == g1) ? b2 : b1);
-          }
-          const bool has1 = g1 != KT::NONE, has2 = g2 != KT::NONE;
-          const int bd = has1 ? KT::dist(g1) : 256;
-          const int bestIdx = has1 ? KT::idx(g1) : 0;
-          const bool accept = accept_rule(M, has1, bd, has1 ? octave_of(bestIdx) : 0, has2, has2 ? KT::dist(g2) : 256, has2 ? octave_of(KT::idx(g2)) : 0);
-          const uint32_t rob = (rfl >> 1) & 1u;
-          if (accept) {
-            nmatches++;
-            if (lane == 0) {
-              if (rob) sOwner[bestIdx] = 0u;
-              __hip_atomic_fetch_max(&sSlot[bestIdx], (int32_t)(((uint32_t)(base + r) << 1) | rob), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
-          if (lane == r) { res_idx = accept ? bestIdx : -1; res_bd = bd <= M.th_dist ? bd : 256; D = 0; }
-          __builtin_amdgcn_wave_barrier();
-#ifdef RESOLVE_STAMPS
-          t_rescan += __builtin_readcyclecounter() - ts0; n_rescan++;
-#endif
-        }
-        s = r + 1;
+        s = r;
+        if (r < cnt) refresh(flagged);  // lane r is now first in line: with its fresh list it decides in the next round
       }
       if (q < nq) {
         if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
@@ -592,9 +622,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       }
     }
 #ifdef RESOLVE_STAMPS
-    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = t_setup; d[1] = t_chunk; d[2] = t_round; d[3] = t_rescan; d[4] = n_rescan; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; d[7] = n_round; }
+    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = n_batch; d[1] = t_chunk; d[2] = t_round; d[3] = t_refresh; d[4] = n_refresh; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; d[7] = n_round; }
 #endif
-    if (lane == 0) { sCmd[0] = 0xffffffffu; if (M.nmatches) M.nmatches[p] = nmatches; }
+    if (lane == 0) { sCmd = -1; if (M.nmatches) M.nmatches[p] = nmatches; }
     __syncthreads();                   // (A) exit command
   }
   __syncthreads();                     // sSlot complete

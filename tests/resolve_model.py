@@ -2,8 +2,8 @@
 
 The reference resolves map points strictly in order (ORBmatcher.cc:75-135): a keypoint taken by an earlier map point with
 observations is skipped by later ones.  The kernel instead lets the 64 queries of a chunk decide in parallel and iterates
-to the unique fix-point of  D_i = f_i(D_0..D_i-1);  a query whose TOPK list is exhausted cuts the prefix and is rescanned
-exactly.  This file restates both in pure Python on abstract candidate lists so that the equivalence (including the
+to the unique fix-point of  D_i = f_i(D_0..D_i-1);  a query whose TOPK list is exhausted cuts the prefix: the prefix is committed and the
+query gets a fresh list (the best REFRESH_K keypoints no committed claim holds) and decides again.  This file restates both in pure Python on abstract candidate lists so that the equivalence (including the
 "withdraw unless committed" rule and the last-writer slot) is tested without a GPU.
 """
 import numpy as np
@@ -43,23 +43,26 @@ def sequential(cands, obs, n, th, ratio, use_second, preclaimed):
     return moq, slot, sobs
 
 
-def decide(lst_full, owner_view, th, ratio, use_second):
-    """Decision from the TOPK prefix of a list; owner_view(k) -> True if claimed for this lane.
-    Returns (accept, rescan, kp)."""
-    top = lst_full[:TOPK]
-    truncated = len(lst_full) >= TOPK          # the kernel sees only "entry TOPK-1 exists"
+REFRESH_K = 4
+
+
+def decide(top, cap, owner_view, th, ratio, use_second):
+    """Decision from a lane's current list `top` (<= cap entries, sorted); owner_view(k) -> True if claimed for this lane.
+    Every candidate that is not in the list (and was unclaimed when the list was made) has key >= top[cap-1].
+    Returns (accept, exhausted, kp)."""
+    truncated = len(top) >= cap                # the kernel sees only "entry cap-1 exists"
     alive = [c for c in top if not owner_view(c[2])]
     found = len(alive)
-    lb = top[TOPK - 1][0] if truncated else None
+    lb = top[cap - 1][0] if truncated else None
     bd = alive[0][0] if found else 256
-    rescan = False
+    exhausted = False
     if truncated:
         if found == 0:
-            rescan = lb <= th
+            exhausted = lb <= th
         elif found == 1 and use_second:
-            rescan = bd <= th and bd > ratio * lb
-    acc = (not rescan) and accept_rule(th, ratio, use_second, alive[0] if found else None, alive[1] if found > 1 else None)
-    return acc, rescan, (alive[0][2] if found else 0)
+            exhausted = bd <= th and bd > ratio * lb
+    acc = (not exhausted) and accept_rule(th, ratio, use_second, alive[0] if found else None, alive[1] if found > 1 else None)
+    return acc, exhausted, (alive[0][2] if found else 0)
 
 
 def speculative(cands, obs, n, th, ratio, use_second, preclaimed, stats=None):
@@ -69,10 +72,28 @@ def speculative(cands, obs, n, th, ratio, use_second, preclaimed, stats=None):
     slotv = [-1] * n
     nq = len(cands)
     moq = [-1] * nq
+
+    def bump(key, by=1):
+        if stats is not None:
+            stats[key] = stats.get(key, 0) + by
+
     for base in range(0, nq, 64):
         cnt = min(64, nq - base)
+        lists = [cands[base + l][:TOPK] if l < cnt else [] for l in range(64)]   # what k_match_scan delivered
+        caps = [TOPK] * 64
         D = [(False, False, 0)] * 64
         s = 0
+        first_round = True
+
+        def refresh(lanes):
+            # new list = the REFRESH_K best candidates that no COMMITTED claim holds (posts are all withdrawn here)
+            assert all(o in (0, FREE) for o in owner), "a post was left behind"
+            for l in lanes:
+                lists[l] = [c for c in cands[base + l] if owner[c[2]] != 0][:REFRESH_K]
+                caps[l] = REFRESH_K
+            bump("refresh_batches", (len(lanes) + 7) // 8)
+            bump("refreshed", len(lanes))
+
         while s < cnt:
             while True:
                 pend = [s <= l < cnt for l in range(64)]
@@ -82,18 +103,22 @@ def speculative(cands, obs, n, th, ratio, use_second, preclaimed, stats=None):
                         owner[D[l][2]] = min(owner[D[l][2]], l + 1)
                 snap = list(owner)                        # every lane reads before anyone withdraws
                 for l in range(64):
-                    if post[l] and snap[D[l][2]] != 0:
+                    if post[l] and snap[D[l][2]] != 0:    # a claim committed since my (stale) decision must survive
                         owner[D[l][2]] = FREE
                 newD = list(D)
                 for l in range(64):
                     if pend[l]:
-                        newD[l] = decide(cands[base + l], lambda k, l=l: snap[k] <= l, th, ratio, use_second)
+                        newD[l] = decide(lists[l], caps[l], lambda k, l=l: snap[k] <= l, th, ratio, use_second)
                 changed = [newD[l] != D[l] for l in range(64)]
                 D = newD
+                bump("rounds")
                 flagged = [l for l in range(64) if pend[l] and D[l][1]]
+                if first_round:
+                    first_round = False
+                    if flagged:                           # exhausted by the claims of earlier chunks: refresh at once
+                        refresh(flagged)
+                        continue
                 r = flagged[0] if flagged else cnt
-                if stats is not None:
-                    stats["rounds"] = stats.get("rounds", 0) + 1
                 if not any(changed[l] and l <= r for l in range(64)):
                     break
             for l in range(s, r):                         # commit the settled prefix
@@ -103,20 +128,9 @@ def speculative(cands, obs, n, th, ratio, use_second, preclaimed, stats=None):
                     if obs[base + l]:
                         owner[k] = 0
                     slotv[k] = max(slotv[k], ((base + l) << 1) | int(obs[base + l]))
-            if r < cnt:                                   # exact rescan with the committed claims
-                alive = [c for c in cands[base + r] if owner[c[2]] != 0]
-                best = alive[0] if alive else None
-                second = alive[1] if len(alive) > 1 else None
-                if accept_rule(th, ratio, use_second, best, second):
-                    k = best[2]
-                    moq[base + r] = k
-                    if obs[base + r]:
-                        owner[k] = 0
-                    slotv[k] = max(slotv[k], ((base + r) << 1) | int(obs[base + r]))
-                D[r] = (False, False, 0)
-                if stats is not None:
-                    stats["rescans"] = stats.get("rescans", 0) + 1
-            s = r + 1
+            s = r
+            if r < cnt:                                   # lane r (and every other exhausted lane) gets a fresh list
+                refresh(flagged)
         assert all(o in (0, FREE) for o in owner), "a post was left behind"
     slot = [v >> 1 if v >= 0 else -1 for v in slotv]
     sobs = [v & 1 if v >= 0 else 0 for v in slotv]

@@ -29,3 +29,4 @@ def test_rounds_are_few():
     stats = {}
     speculative(cands, obs, 150, 100, 0.8, True, pre, stats)
     assert stats["rounds"] < 192  # fewer rounds than queries: the point of the formulation
+    assert stats.get("refresh_batches", 0) <= stats.get("refreshed", 0)

@@ -35,7 +35,7 @@ rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(fs), cap, C.c_voi
                                                  C.c_void_p(nm.data_ptr()), None)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
-names = ["setup", "chunk_setup", "rounds+commit", "rescans", "n_rescan", "total", "nq", "n_round"]
+names = ["refresh_batches", "chunk_setup", "rounds+commit", "refreshes", "n_refreshed", "total", "nq", "n_round"]
 m = d.mean(axis=0)
 for n, x in zip(names, m): print("%-18s %12.0f" % (n, x))
-print("cycles per round: %.0f   per rescan: %.0f   rounds per query: %.2f" % (m[2] / max(m[7], 1), m[3] / max(m[4], 1), m[7] / m[6]))
+print("cycles per round: %.0f   per refresh batch: %.0f   rounds per query: %.2f" % (m[2] / max(m[7], 1), m[3] / max(m[0], 1), m[7] / m[6]))
