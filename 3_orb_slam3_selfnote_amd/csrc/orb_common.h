@@ -41,6 +41,7 @@ struct LevelGeom {
   int xtabBase, ytabBase;
   // blur tiles
   int tilesX, tilesY, tileBase;
+  uint32_t rowTileMagic;  // floor(2^32 / row tiles of k_resize), see xcd_map
 };
 
 struct FrameParams {
@@ -65,6 +66,8 @@ struct FrameParams {
   int32_t *candCnt;                 // [frame][nlevels] dense candidate count
   const int2 *xtab, *ytab;          // resize tables {src index, a0 | a1<<16}
   const int8_t *disc;               // ORB_DISC_PIXELS x (u, v)
+  const uint32_t *cells;            // FAST cell records, 8 words each (orbx_configure), same for every frame
+  uint32_t magicCells, magicTiles, magicKpBlk;  // floor(2^32 / items per frame) of k_fast, k_blur, k_describe (xcd_map)
   int totalTiles;                   // blur tiles per frame
   int totalCells;                   // FAST cells per frame
   int totalKp;                      // sum of kpCap

@@ -23,19 +23,25 @@ __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 // (ORBextractor.cc:452-467 always yields umax = 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 for HALF_PATCH_SIZE 15;
 // orbx_create re-derives umax at run time and refuses to start if it differs).  Padded to 768 with (0,0), which
 // contributes u*I = v*I = 0 to the moments.
-struct DiscTab { int8_t u[768]; int8_t v[768]; };
+// Stored per lane: lane L handles disc pixels L, 64+L, ..., 704+L; its twelve u offsets are bytes 0..11 and its twelve
+// v offsets bytes 12..23 of w[L][0..5], so one lane fetches its share of the table with two wide loads.
+struct DiscTab { uint32_t w[64][6]; };
 constexpr DiscTab make_disc_tab() {
   DiscTab t{};
   const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   int n = 0;
   for (int v = -15; v <= 15; v++) {
     const int d = umax[v < 0 ? -v : v];
-    for (int u = -d; u <= d; u++) { t.u[n] = (int8_t)u; t.v[n] = (int8_t)v; n++; }
+    for (int u = -d; u <= d; u++) {
+      const int lane = n & 63, k = n >> 6;  // pixel n = k * 64 + lane
+      t.w[lane][k >> 2] |= (uint32_t)(uint8_t)(int8_t)u << (8 * (k & 3));
+      t.w[lane][3 + (k >> 2)] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
+      n++;
+    }
   }
-  for (; n < 768; n++) { t.u[n] = 0; t.v[n] = 0; }
-  return t;
+  return t;  // pixels 749..767 stay (0, 0)
 }
-__constant__ DiscTab c_disc = make_disc_tab();
+__constant__ __attribute__((aligned(16))) DiscTab c_disc = make_disc_tab();
 
 // ------------------------------------------------------------------------------------------------------------
 // small helpers
@@ -60,21 +66,18 @@ __device__ __forceinline__ const uint8_t *level_plane(const FrameParams &P, int 
 // therefore placed on XCD f % 8: neighbouring FAST cells / blur tiles / keypoint patches of one frame share cache
 // lines and halo rows, and with this mapping they are fetched into ONE L2 instead of up to eight.  Placement only
 // affects speed, never results.  Grid: 1-D, nframes * nitems blocks.
-__device__ __forceinline__ void xcd_map(int nitems, int nframes, int &frame, int &item) {
+// magic = floor(2^32 / nitems) (host): the quotient estimate is at most one too small, one correction makes it exact.
+__device__ __forceinline__ void xcd_map(int nitems, uint32_t magic, int nframes, int &frame, int &item) {
   const unsigned b = blockIdx.x;
   const unsigned full = (unsigned)(nframes & ~7);
   const unsigned nfull = full * (unsigned)nitems;
-  if (b < nfull) {
-    const unsigned x = b & 7u, q = b >> 3;
-    const unsigned g = q / (unsigned)nitems;
-    frame = (int)(x + 8u * g);
-    item = (int)(q - g * (unsigned)nitems);
-  } else {
-    const unsigned r = b - nfull;
-    const unsigned g = r / (unsigned)nitems;
-    frame = (int)(full + g);
-    item = (int)(r - g * (unsigned)nitems);
-  }
+  const bool inFull = b < nfull;
+  const unsigned q = inFull ? (b >> 3) : (b - nfull);
+  unsigned g = __umulhi(q, magic);
+  unsigned r = q - g * (unsigned)nitems;
+  if (r >= (unsigned)nitems) { g++; r -= (unsigned)nitems; }
+  frame = (int)(inFull ? (b & 7u) + 8u * g : full + g);
+  item = (int)r;
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const LevelGeom Gs = P.geom[level - 1];
   const int tid = threadIdx.x;
   int frame, rowTile;
-  xcd_map((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, P.nframes, frame, rowTile);
+  xcd_map((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, G.rowTileMagic, P.nframes, frame, rowTile);
   const int dy0 = rowTile * RESIZE_ROWS;
   const int nrows = min(RESIZE_ROWS, G.h - dy0);
   int spitch;
@@ -226,30 +229,32 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
 // "any corner at iniTh" vote and for the raster-order compaction.  Output: per-cell slot list, packed
 // (response<<24 | y<<12 | x) in detection-rectangle coordinates, raster order inside the cell.
 // ------------------------------------------------------------------------------------------------------------
+typedef short pk16 __attribute__((ext_vector_type(2)));  // two signed 16-bit lanes in one VGPR (v_pk_*_i16)
 __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pitch FAST_TILE_PITCH */) {
   constexpr int Pt = FAST_TILE_PITCH;
   const int v = c[0];
-  int d[16];
-  d[0] = v - c[3 * Pt + 0];   d[1] = v - c[3 * Pt + 1];   d[2] = v - c[2 * Pt + 2];   d[3] = v - c[1 * Pt + 3];
-  d[4] = v - c[3];            d[5] = v - c[-1 * Pt + 3];  d[6] = v - c[-2 * Pt + 2];  d[7] = v - c[-3 * Pt + 1];
-  d[8] = v - c[-3 * Pt];      d[9] = v - c[-3 * Pt - 1];  d[10] = v - c[-2 * Pt - 2]; d[11] = v - c[-1 * Pt - 3];
-  d[12] = v - c[-3];          d[13] = v - c[1 * Pt - 3];  d[14] = v - c[2 * Pt - 2];  d[15] = v - c[3 * Pt - 1];
-  // sliding window min / max of length 9 on the circular sequence by doubling: 2, 4, 8, then +1
-  int mn[16], mx[16];
+  // d[k] = (v - c_k, c_k - v) as two signed 16-bit halves: ONE packed min/max network yields the bright-centre margin
+  // (low half) and the dark-centre margin (high half).
+  const pk16 V2 = {(short)v, (short)-v};
+  const pk16 K = {(short)-1, (short)1};
+  pk16 d[16];
+#define ORB_RING(k, off) { const short cc = (short)c[off]; const pk16 C = {cc, cc}; d[k] = C * K + V2; }
+  ORB_RING(0, 3 * Pt + 0)   ORB_RING(1, 3 * Pt + 1)   ORB_RING(2, 2 * Pt + 2)    ORB_RING(3, 1 * Pt + 3)
+  ORB_RING(4, 3)            ORB_RING(5, -1 * Pt + 3)  ORB_RING(6, -2 * Pt + 2)   ORB_RING(7, -3 * Pt + 1)
+  ORB_RING(8, -3 * Pt)      ORB_RING(9, -3 * Pt - 1)  ORB_RING(10, -2 * Pt - 2)  ORB_RING(11, -1 * Pt - 3)
+  ORB_RING(12, -3)          ORB_RING(13, 1 * Pt - 3)  ORB_RING(14, 2 * Pt - 2)   ORB_RING(15, 3 * Pt - 1)
+#undef ORB_RING
+  // sliding window minimum of length 9 on the circular sequence by doubling: 2, 4, 8, then +1
+  pk16 m2[16], m4[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-  int mn4[16], mx4[16];
+  for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-  for (int k = 0; k < 16; k++) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
-  int A = -255, B = 255;
+  for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+  pk16 A = {(short)-255, (short)-255};
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    int m8 = min(mn4[k], mn4[(k + 4) & 15]);
-    int x8 = max(mx4[k], mx4[(k + 4) & 15]);
-    A = max(A, min(m8, d[(k + 8) & 15]));  // bright centre: all of the arc darker by at least A
-    B = min(B, max(x8, d[(k + 8) & 15]));  // dark centre:  -B = largest margin
-  }
-  int S = max(A, -B);
+  for (int k = 0; k < 16; k++)
+    A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+  const int S = max((int)A.x, (int)A.y);  // all of some arc darker by A.x, or brighter by A.y
   return min(max(S, 0), 255);
 }
 
@@ -270,7 +275,10 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
   return (dd | bb) < 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast(FrameParams P) {
+#ifndef FAST_NT
+#define FAST_NT 256
+#endif
+__global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[60 * 60];
@@ -278,31 +286,31 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   __shared__ uint32_t sCount, sNList, sNKept, sNOut;
   const int tid = threadIdx.x, lane = tid & 63;
   int cellId, frame;
-  xcd_map(P.totalCells, P.nframes, frame, cellId);
-  int level = 0;
-  for (int l = 1; l < P.nlevels; l++)
-    if (cellId >= P.geom[l].cellBase) level = l;
-  const LevelGeom G = P.geom[level];
-  const int c = cellId - G.cellBase;
-  const int ci = c / G.nCols, cj = c - ci * G.nCols;
+  xcd_map(P.totalCells, P.magicCells, P.nframes, frame, cellId);
+  // cell record (orbx_configure, ORBextractor.cc:787-803): one 32-byte scalar load instead of a level search plus
+  // a dozen dependent geometry loads per workgroup
+  const uint4 r0 = reinterpret_cast<const uint4 *>(P.cells)[2 * cellId], r1 = reinterpret_cast<const uint4 *>(P.cells)[2 * cellId + 1];
+  const int iniX = (int)(r0.x & 0xffffu), iniY = (int)(r0.x >> 16);
+  const int tw = (int)(r0.y & 0xffu), th = (int)((r0.y >> 8) & 0xffu), level = (int)((r0.y >> 16) & 0xffu), cw = tw - 6, ch = th - 6;
+  const uint32_t baseX = r0.z & 0xffffu, baseY = r0.z >> 16;  // cj * wCell, ci * hCell
+  const uint32_t cellCap = r1.x;
   uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cell_fs + cellId;
-  // ORBextractor.cc:787-803
-  const int iniX = ORB_MIN_BORDER + cj * G.wCell, iniY = ORB_MIN_BORDER + ci * G.hCell;
-  const int maxX = min(iniX + G.wCell + 6, G.maxBorderX), maxY = min(iniY + G.hCell + 6, G.maxBorderY);
-  const int tw = maxX - iniX, th = maxY - iniY, cw = tw - 6, ch = th - 6;
-  if (iniX >= G.maxBorderX - 6 || iniY >= G.maxBorderY - 3 || cw <= 0 || ch <= 0) {
+  if (!(r0.y >> 24)) {  // cell outside the detection rectangle
     if (tid == 0) *cellCnt = 0;
     return;
   }
   int pitch;
-  const uint8_t *img = level_plane(P, frame, level, pitch);
+  const uint8_t *img;
+  if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
+  else { pitch = (int)r1.y; img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)r1.w << 32) | r1.z); }
+
   // ---- tile -> LDS.  Aligned path: dword loads of the columns [iniX & ~3, ...), tile column 0 = image column ax.
   const int ax = iniX & ~3, ox = iniX - ax;           // ox: offset of the cell's first column inside the tile
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
   if (aligned) {
     const int ndw = (ox + tw + 3) >> 2;               // dwords per tile row (<= 18)
     const uint32_t magic = 0xffffffffu / (uint32_t)ndw + 1u;
-    for (int idx = tid; idx < ndw * th; idx += 256) {
+    for (int idx = tid; idx < ndw * th; idx += FAST_NT) {
       const int r = (int)__umulhi((uint32_t)idx, magic), d = idx - r * ndw;
       // the last dword of a row may reach past the image row; it stays inside the plane's pitch padding / next row
       const uint32_t v = *reinterpret_cast<const uint32_t *>(img + (size_t)(iniY + r) * pitch + ax + 4 * d);
@@ -310,22 +318,21 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
     }
   } else {
     const uint32_t magic = 0xffffffffu / (uint32_t)tw + 1u;
-    for (int idx = tid; idx < tw * th; idx += 256) {
+    for (int idx = tid; idx < tw * th; idx += FAST_NT) {
       const int r = (int)__umulhi((uint32_t)idx, magic), cc = idx - r * tw;
       sT[r * FAST_TILE_PITCH + ox + cc] = img[(size_t)(iniY + r) * pitch + iniX + cc];
     }
   }
-  for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += 256) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
+  for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
   if (tid == 0) { sCount = 0; sNList = 0; sNKept = 0; sNOut = 0; }
   __syncthreads();
-  const int npx = cw * ch;
   const int tmin = min(P.iniTh, P.minTh);
   const uint32_t magicw = 0xffffffffu / (uint32_t)cw + 1u;  // p / cw for p < 2^16 (exact: p*cw < 2^32)
   // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list
-  for (int p0 = 0; p0 < npx; p0 += 256) {
+  for (int p0 = 0; p0 < cw * ch; p0 += FAST_NT) {
     const int p = p0 + tid;
     bool pass = false;
-    if (p < npx) {
+    if (p < cw * ch) {
       const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
       pass = fast_compass_test(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3], tmin);
     }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   __syncthreads();
   // ---- pass 2: full 16-pixel score for the survivors only
   const int nlist = (int)sNList;
-  for (int e = tid; e < nlist; e += 256) {
+  for (int e = tid; e < nlist; e += FAST_NT) {
     const int p = sList[e];
     const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
     const int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3]);
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   __syncthreads();
   // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list; vote for
   // the iniThFAST set.  Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
-  for (int e = tid; e < nlist; e += 256) {
+  for (int e = tid; e < nlist; e += FAST_NT) {
     const int p = sList[e];
     const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
     const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
@@ -365,23 +372,23 @@ __global__ __launch_bounds__(256) void k_fast(FrameParams P) {
   const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
   uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (4752 B >= 1024 entries): keeps LDS at ~20 KB = 8 workgroups per CU
   const int nkept = (int)sNKept;
-  for (int e = tid; e < nkept; e += 256) {
+  for (int e = tid; e < nkept; e += FAST_NT) {
     const uint32_t v = sKept[e];
     if ((int)(v >> 16) > thr) sOut[atomicAdd(&sNOut, 1u)] = v;
   }
   __syncthreads();
   // ---- pass 4: cv::FAST emits rows ascending, x ascending = ascending p: rank by counting (lists are short)
   const int nout = (int)sNOut;
-  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase + (size_t)c * G.cellCap;
-  for (int e = tid; e < nout; e += 256) {
+  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
+  for (int e = tid; e < nout; e += FAST_NT) {
     const uint32_t v = sOut[e], p = v & 0xffffu;
     uint32_t rank = 0;
     for (int i = 0; i < nout; i++) rank += ((sOut[i] & 0xffffu) < p) ? 1u : 0u;
     const int y = (int)__umulhi(p, magicw), x = (int)p - y * cw;
-    const uint32_t X = (uint32_t)(cj * G.wCell + x + 3), Y = (uint32_t)(ci * G.hCell + y + 3);
-    if (rank < (uint32_t)G.cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
+    const uint32_t X = baseX + (uint32_t)(x + 3), Y = baseY + (uint32_t)(y + 3);
+    if (rank < cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
   }
-  if (tid == 0) *cellCnt = min((uint32_t)nout, (uint32_t)G.cellCap);
+  if (tid == 0) *cellCnt = min((uint32_t)nout, cellCap);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -695,10 +702,11 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   __shared__ uint32_t sRow[38 * 64];
   const int tid = threadIdx.x;
   int tile, frame;
-  xcd_map(P.totalTiles, P.nframes, frame, tile);
+  xcd_map(P.totalTiles, P.magicTiles, P.nframes, frame, tile);
   int level = 0;
-  for (int l = 1; l < P.nlevels; l++)
-    if (tile >= P.geom[l].tileBase) level = l;
+#pragma unroll
+  for (int l = 1; l < ORB_MAXL; l++)  // constant trip count: the scalar loads are independent and issue together
+    if (l < P.nlevels && tile >= P.geom[l].tileBase) level = l;
   const LevelGeom G = P.geom[level];
   const int t = tile - G.tileBase;
   const int ty = t / G.tilesX, tx = t - ty * G.tilesX;
@@ -807,24 +815,35 @@ struct KpOut { float x, y, size, angle, response; int32_t octave, class_id; };
 __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const int lane = threadIdx.x & 63;
   int frame, blk;
-  xcd_map((P.totalKp + 3) / 4, P.nframes, frame, blk);
-  const int j = blk * 4 + (threadIdx.x >> 6);
+  xcd_map((P.totalKp + 3) / 4, P.magicKpBlk, P.nframes, frame, blk);
+  const int j = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: scalar loads below
   if (j >= P.totalKp) return;
+  // Everything that does not depend on the keypoint is requested first (one memory latency for all of it): my share of
+  // the disc and pattern tables, the level counts, the keypoint itself (its slot j is level-independent).
+  const uint32_t packed = P.lkp[(size_t)frame * P.lkp_fs + j];
+  const uint32_t rk = P.lrank[(size_t)frame * P.lkp_fs + j];
+  const uint4 dw0 = *reinterpret_cast<const uint4 *>(&c_disc.w[lane][0]);
+  const uint2 dw1 = *reinterpret_cast<const uint2 *>(&c_disc.w[lane][4]);
+  uint32_t pw[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) pw[r] = reinterpret_cast<const uint32_t *>(c_pattern)[r * 64 + lane];  // x0, y0, x1, y1 as int8
+  const int32_t *lc = P.lcnt + (size_t)frame * P.nlevels * 2;
   int level = 0;
-  for (int l = 1; l < P.nlevels; l++)
-    if (j >= P.geom[l].kpBase) level = l;
+#pragma unroll
+  for (int l = 1; l < ORB_MAXL; l++)
+    if (l < P.nlevels && j >= P.geom[l].kpBase) level = l;
+  int nTot = 0, lapBefore = 0, monoBefore = 0, myCount = 0;
+#pragma unroll
+  for (int l = 0; l < ORB_MAXL; l++)
+    if (l < P.nlevels) {
+      const int c = lc[l * 2], lp = lc[l * 2 + 1];
+      nTot += c;
+      if (l < level) { lapBefore += lp; monoBefore += c - lp; }
+      if (l == level) myCount = c;
+    }
   const LevelGeom G = P.geom[level];
   const int i = j - G.kpBase;
-  const int32_t *lc = P.lcnt + (size_t)frame * P.nlevels * 2;
-  if (i >= lc[level * 2]) return;
-  int nTot = 0, lapBefore = 0, monoBefore = 0;
-  for (int l = 0; l < P.nlevels; l++) {
-    int c = lc[l * 2], lp = lc[l * 2 + 1];
-    nTot += c;
-    if (l < level) { lapBefore += lp; monoBefore += c - lp; }
-  }
-  const uint32_t packed = P.lkp[(size_t)frame * P.lkp_fs + G.kpBase + i];
-  const uint32_t rk = P.lrank[(size_t)frame * P.lkp_fs + G.kpBase + i];
+  if (i >= myCount) return;
   const int X = (int)(packed & 0xfff) + ORB_MIN_BORDER, Y = (int)((packed >> 12) & 0xfff) + ORB_MIN_BORDER;
   const int dst = (rk & 0x8000u) ? nTot - 1 - (lapBefore + (int)(rk & 0x7fff)) : monoBefore + (int)(rk & 0x7fff);
 
@@ -834,8 +853,14 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const uint8_t *centre = img + (size_t)Y * pitch + X;
   int m10 = 0, m01 = 0;
   int dv[12], du[12], dval[12];
+  {
+    const uint32_t uw[3] = {dw0.x, dw0.y, dw0.z}, vw[3] = {dw0.w, dw1.x, dw1.y};
 #pragma unroll
-  for (int t = 0; t < 12; t++) { du[t] = c_disc.u[t * 64 + lane]; dv[t] = c_disc.v[t * 64 + lane]; }
+    for (int t = 0; t < 12; t++) {
+      du[t] = (int)(int8_t)(uw[t >> 2] >> (8 * (t & 3)));
+      dv[t] = (int)(int8_t)(vw[t >> 2] >> (8 * (t & 3)));
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 12; t++) dval[t] = centre[dv[t] * pitch + du[t]];
 #pragma unroll
@@ -854,9 +879,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   int o0[4], o1[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t pw = reinterpret_cast<const uint32_t *>(c_pattern)[r * 64 + lane];  // x0, y0, x1, y1 as int8
-    const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff);
-    const float x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
+    const float x0 = (float)(int8_t)(pw[r] & 0xff), y0 = (float)(int8_t)((pw[r] >> 8) & 0xff);
+    const float x1 = (float)(int8_t)((pw[r] >> 16) & 0xff), y1 = (float)(int8_t)(pw[r] >> 24);
     o0[r] = __float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b);
     o1[r] = __float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b);
   }

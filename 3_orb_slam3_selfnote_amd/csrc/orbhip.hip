@@ -66,7 +66,7 @@ struct orbx_handle {
   int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
-  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_xtab,
+  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_xtab,
       d_ytab, d_disc;
   DevBuf d_img, d_okps, d_odesc, d_ocounts;  // staging for the host entry point
   hipStream_t stream = nullptr;
@@ -156,8 +156,11 @@ orbx_t *orbx_create(int nfeatures, float scaleFactor_, int nlevels, int iniThFAS
   if ((int)disc.size() != 2 * ORB_DISC_PIXELS) { delete h; return nullptr; }
   {
     const DiscTab ref = make_disc_tab();  // the kernels' compile-time table must equal what ORBextractor.cc:452-467 derives
-    for (int i = 0; i < ORB_DISC_PIXELS; i++)
-      if (ref.u[i] != disc[2 * i] || ref.v[i] != disc[2 * i + 1]) { delete h; return nullptr; }
+    for (int i = 0; i < ORB_DISC_PIXELS; i++) {
+      const int lane = i & 63, k = i >> 6;
+      const int8_t u = (int8_t)(ref.w[lane][k >> 2] >> (8 * (k & 3))), v = (int8_t)(ref.w[lane][3 + (k >> 2)] >> (8 * (k & 3)));
+      if (u != disc[2 * i] || v != disc[2 * i + 1]) { delete h; return nullptr; }
+    }
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
   if (h->d_disc.reserve(disc.size()) != hipSuccess ||
@@ -174,7 +177,7 @@ void orbx_destroy(orbx_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
-                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
   if (h->ev_ok)
     for (auto &e : h->ev) (void)hipEventDestroy(e);
@@ -202,6 +205,9 @@ int orbx_get_features_per_level(const orbx_t *h, int *n) {
   for (int i = 0; i < h->nlevels; i++) n[i] = h->mnFeaturesPerLevel[i];
   return h->nlevels;
 }
+
+// floor(2^32 / n) for xcd_map's division by multiplication (n == 1: the estimate q-1 is corrected on the device)
+static uint32_t magic_div(uint32_t n) { return n <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / n); }
 
 int orbx_max_keypoints(const orbx_t *h) { return h ? h->maxKeypoints : ORBX_E_ARG; }
 
@@ -301,6 +307,30 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
     }
   }
   if (slots > (1 << 30)) { h->err = "workspace too large"; return ORBX_E_ARG; }
+  // FAST cell records (k_fast): window of every cell as the reference's double loop derives it, ORBextractor.cc:787-803
+  std::vector<uint32_t> cellrec((size_t)std::max(cells, 1) * 8, 0u);
+  for (int l = 0; l < nl; l++) {
+    LevelGeom &G = g[l];
+    G.rowTileMagic = magic_div((uint32_t)((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS));
+    for (int ci = 0; ci < G.nRows; ci++)
+      for (int cj = 0; cj < G.nCols; cj++) {
+        const int c = ci * G.nCols + cj;
+        uint32_t *R = &cellrec[(size_t)(G.cellBase + c) * 8];
+        const int iniX = ORB_MIN_BORDER + cj * G.wCell, iniY = ORB_MIN_BORDER + ci * G.hCell;
+        const int maxX = std::min(iniX + G.wCell + 6, G.maxBorderX), maxY = std::min(iniY + G.hCell + 6, G.maxBorderY);
+        const int tw = maxX - iniX, th = maxY - iniY;
+        const bool valid = !(iniX >= G.maxBorderX - 6 || iniY >= G.maxBorderY - 3 || tw - 6 <= 0 || th - 6 <= 0);
+        if (valid && (tw > FAST_TILE_PITCH - 7 || th > FAST_TILE_ROWS)) { h->err = "FAST cell larger than the LDS tile"; return ORBX_E_ARG; }
+        R[0] = (uint32_t)iniX | ((uint32_t)iniY << 16);
+        R[1] = valid ? ((uint32_t)tw | ((uint32_t)th << 8) | ((uint32_t)l << 16) | (1u << 24)) : ((uint32_t)l << 16);
+        R[2] = (uint32_t)(cj * G.wCell) | ((uint32_t)(ci * G.hCell) << 16);
+        R[3] = (uint32_t)(G.slotBase + c * G.cellCap);
+        R[4] = (uint32_t)G.cellCap;
+        R[5] = (uint32_t)G.pitch;
+        R[6] = (uint32_t)(G.off & 0xffffffffu);
+        R[7] = (uint32_t)((uint64_t)G.off >> 32);
+      }
+  }
   h->geom = g;
   h->pyr_fs = std::max<size_t>(pyr, 256);
   h->blur_fs = blur;
@@ -325,6 +355,8 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_lrank.reserve(sizeof(uint16_t) * (size_t)h->lkp_fs * B));
   XCHECK(h, h->d_lcnt.reserve(sizeof(int32_t) * 2 * nl * B));
   XCHECK(h, h->d_candCnt.reserve(sizeof(int32_t) * nl * B));
+  XCHECK(h, h->d_cells.reserve(sizeof(uint32_t) * cellrec.size()));
+  XCHECK(h, hipMemcpy(h->d_cells.p, cellrec.data(), sizeof(uint32_t) * cellrec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_xtab.reserve(sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
   XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
   if (!xtab.empty()) XCHECK(h, hipMemcpy(h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
@@ -400,6 +432,10 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   P.disc = (const int8_t *)h->d_disc.p;
   P.totalTiles = h->totalTiles;
   P.totalCells = h->totalCells;
+  P.cells = (const uint32_t *)h->d_cells.p;
+  P.magicCells = magic_div((uint32_t)std::max(h->totalCells, 1));
+  P.magicTiles = magic_div((uint32_t)std::max(h->totalTiles, 1));
+  P.magicKpBlk = magic_div((uint32_t)std::max((h->totalKp + 3) / 4, 1));
   P.totalKp = h->totalKp;
   P.octCap = h->octCap;
   P.out_kps = d_kps;
@@ -417,7 +453,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
   }
   if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
-  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(256), 0, s, P);
+  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
   hipLaunchKernelGGL(k_octree<256>, dim3(h->nlevels, nframes), dim3(256), 72 * (size_t)h->octCap + 128, s, P, (uint32_t *)h->d_cellOff.p);
   if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
