@@ -80,10 +80,18 @@ __device__ __forceinline__ void xcd_map(int nitems, uint32_t magic, int nframes,
   item = (int)r;
 }
 
+// Wave-wide sum through DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31): no LDS traffic; the result is uniform.
+// All 64 lanes must be active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false); }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
+  v += dpp_or_zero<0x111, 0xf>(v);
+  v += dpp_or_zero<0x112, 0xf>(v);
+  v += dpp_or_zero<0x114, 0xf>(v);
+  v += dpp_or_zero<0x118, 0xf>(v);
+  v += dpp_or_zero<0x142, 0xa>(v);
+  v += dpp_or_zero<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // inclusive scan inside a wavefront
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 // ------------------------------------------------------------------------------------------------------------
 struct OctNode { short ulx, urx, uly, bry; };
 
-template <int NT>
+template <int NT, bool CELLS_LDS>
 __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffScratch) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int CAP = P.octCap;
@@ -436,9 +444,13 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   uint16_t *knode = P.knode + (size_t)frame * P.cand_fs + G.candBase;
 
   // ---- A. compact the per-cell slot lists into vToDistributeKeys order (cells row-major, raster inside) ----
+  // Cell offsets by a workgroup scan (kept in LDS when they fit: CELLS_LDS), then one thread per candidate finds its
+  // cell by bisection and copies its slot: every global access of this phase is independent of the others, so the
+  // phase costs a few memory latencies instead of one per cell.
   const int ncell = G.nCols * G.nRows;
   const uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cell_fs + G.cellBase;
-  uint32_t *cellOff = cellOffScratch + (size_t)frame * P.cell_fs + G.cellBase;
+  uint32_t *cellOffG = cellOffScratch + (size_t)frame * P.cell_fs + G.cellBase;
+  uint32_t *cellOffL = sw + (NT / 64 + 2);          // ncell + 1 words behind the scan scratch (CELLS_LDS only)
   uint32_t carry = 0;
   for (int base = 0; base < ncell; base += NT) {
     int i = base + tid;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     __syncthreads();
     uint32_t woff = 0, tot = 0;
     for (int w = 0; w < NW; w++) { uint32_t s = sw[w]; if (w < wid) woff += s; tot += s; }
-    if (i < ncell) cellOff[i] = carry + woff + inc - v;
+    if (i < ncell) { if (CELLS_LDS) cellOffL[i] = carry + woff + inc - v; else cellOffG[i] = carry + woff + inc - v; }
     carry += tot;
     __syncthreads();
   }
@@ -458,13 +470,24 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     if (tid == 0) { lcnt[0] = 0; lcnt[1] = 0; }
     return;
   }
-  __syncthreads();  // cellOff visible to the whole workgroup
+  __syncthreads();  // cell offsets visible to the whole workgroup
   {
     const uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase;
-    for (int cidx = wid; cidx < ncell; cidx += NW) {
-      uint32_t cnt = cellCnt[cidx], off = cellOff[cidx];
-      for (uint32_t j = lane; j < cnt; j += 64)
-        if (off + j < (uint32_t)n) cand[off + j] = slots[(size_t)cidx * G.cellCap + j];
+    if (CELLS_LDS) {
+      for (int k = tid; k < n; k += NT) {
+        int lo = 0, hi = ncell - 1;                  // last cell whose offset is <= k (empty cells share offsets)
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (cellOffL[mid] <= (uint32_t)k) lo = mid; else hi = mid - 1;
+        }
+        cand[k] = slots[(size_t)lo * G.cellCap + ((uint32_t)k - cellOffL[lo])];
+      }
+    } else {
+      for (int cidx = wid; cidx < ncell; cidx += NW) {
+        uint32_t cnt = cellCnt[cidx], off = cellOffG[cidx];
+        for (uint32_t j = lane; j < cnt; j += 64)
+          if (off + j < (uint32_t)n) cand[off + j] = slots[(size_t)cidx * G.cellCap + j];
+      }
     }
   }
   __syncthreads();

@@ -63,6 +63,8 @@ struct orbx_handle {
   int rows = 0, cols = 0, max_batch = 0;
   std::vector<LevelGeom> geom;
   size_t pyr_fs = 0, blur_fs = 0, slot_fs = 0;
+  bool octCellsLds = false;
+  size_t octLds = 0;
   int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
@@ -361,10 +363,18 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
   if (!xtab.empty()) XCHECK(h, hipMemcpy(h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
   if (!ytab.empty()) XCHECK(h, hipMemcpy(h->d_ytab.p, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
-  const size_t lds = 72 * (size_t)octCap + 128;
+  // k_octree LDS: node arrays (72 B per node) + scan scratch, plus the level's cell offsets when they fit
+  int maxCells = 1;
+  for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, g[l].nCols * g[l].nRows);
+  size_t lds = 72 * (size_t)octCap + 128;
   if (lds > 160 * 1024 - 256) { h->err = "nfeatures too large for the LDS-resident octree"; return ORBX_E_ARG; }
-  if (lds > 48 * 1024)
-    XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  h->octCellsLds = lds + 4 * ((size_t)maxCells + 1) <= 96 * 1024;
+  if (h->octCellsLds) lds += 4 * ((size_t)maxCells + 1);
+  h->octLds = lds;
+  if (lds > 48 * 1024) {
+    if (h->octCellsLds) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   h->rows = rows;
   h->cols = cols;
   h->max_batch = max_batch;
@@ -455,7 +465,8 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
-  hipLaunchKernelGGL(k_octree<256>, dim3(h->nlevels, nframes), dim3(256), 72 * (size_t)h->octCap + 128, s, P, (uint32_t *)h->d_cellOff.p);
+  if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels, nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels, nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
   if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[4], s));
