@@ -437,7 +437,10 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int NW = NT / 64;
-  const int level = blockIdx.x, frame = blockIdx.y;
+  // 1-D grid, level-major: workgroups are dealt round-robin over the 8 XCDs by block index, so frame f of every level
+  // lands on XCD f % 8 (a (level, frame) 2-D grid put ALL level-0 workgroups, the long ones, on one XCD: 2.2x slower),
+  // and the long level-0 workgroups are dispatched first.
+  const int level = (int)(blockIdx.x / (unsigned)P.nframes), frame = (int)(blockIdx.x - (unsigned)level * (unsigned)P.nframes);
   const LevelGeom G = P.geom[level];
   int32_t *lcnt = P.lcnt + ((size_t)frame * P.nlevels + level) * 2;
   uint32_t *cand = P.cand + (size_t)frame * P.cand_fs + G.candBase;

@@ -465,8 +465,8 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
-  if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels, nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
-  else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels, nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
   if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(h->ev[4], s));
