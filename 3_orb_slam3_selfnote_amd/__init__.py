@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -112,6 +112,9 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]
     L.orbm_search_by_projection_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, f32, i32, i32,
                                                          vp, vp, vp, vp, vp, vp]
+    L.orbm_search_by_projection_fisheye.argtypes = [vp, vp, i32, vp, vp, vp, f32, i32, vp, vp, vp, vp]
+    L.orbm_search_by_projection_last_frame_fisheye.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32,
+                                                               i32, i32, vp, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
@@ -436,6 +439,67 @@ class ORBmatcher:
         self._check(rc, "orbm_search_by_projection_last_frame")
         if rc < 0:
             raise OrbError("orbm_search_by_projection_last_frame rc=%d" % rc)
+        return rc
+
+    def SearchByProjectionFisheye(self, F, n_left, left_to_right, right_to_left, mp_desc, scale_factors, th,
+                                  in_view, projX, projY, viewCos, level, in_view_r, projXR, projYR, viewCosR, levelR, mp_obs=None):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th, ...) for a fisheye-stereo frame (Nleft != -1) --
+        ORBmatcher.cc:44-214 complete.  F: FrameView over mvKeys ++ mvKeysRight / mDescriptors (N = Nleft + Nright).
+        Returns (nmatches, match_left[nmp], match_right[nmp]) with right matches as indices into the right image."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf = a(scale_factors, np.float32)
+        nmp = len(level)
+        lvl, lvlR = a(level, np.int32), a(levelR, np.int32)
+
+        def radius_of(vc, lv, with_th):
+            r = np.where(a(vc, np.float32).astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)  # :216-222
+            if with_th and float(np.float32(th)) != 1.0:
+                r = (r * np.float32(th)).astype(np.float32)                                                                  # :69-70
+            return (r * sf[np.clip(lv, 0, len(sf) - 1)]).astype(np.float32)
+
+        obs = np.ones(nmp, np.uint8) if mp_obs is None else a(mp_obs, np.uint8)
+        nq = 2 * nmp
+        u, v, rad = np.zeros(nq, np.float32), np.zeros(nq, np.float32), np.zeros(nq, np.float32)
+        minl, maxl, flags = np.zeros(nq, np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.uint8)
+        u[0::2], v[0::2], rad[0::2] = a(projX, np.float32), a(projY, np.float32), radius_of(viewCos, lvl, True)
+        u[1::2], v[1::2], rad[1::2] = a(projXR, np.float32), a(projYR, np.float32), radius_of(viewCosR, lvlR, False)  # :148: no th
+        minl[0::2], maxl[0::2] = lvl - 1, lvl
+        minl[1::2], maxl[1::2] = lvlR - 1, lvlR
+        flags[0::2] = (a(in_view, np.uint8) & 1) | ((obs & 1) << 1)
+        flags[1::2] = ((a(in_view_r, np.uint8) & 1) & (lvlR != -1)) | ((obs & 1) << 1)                                 # :147
+        qdesc = np.repeat(a(mp_desc, np.uint8).reshape(nmp, 32), 2, axis=0).copy()
+        l2r = None if left_to_right is None else a(left_to_right, np.int32)
+        r2l = None if right_to_left is None else a(right_to_left, np.int32)
+        qs = QueryStruct(nq, _p(qdesc), _p(u), _p(v), _p(rad), _p(minl), _p(maxl), None, _p(flags))
+        fs = F.struct()
+        moq = np.full(nq, -1, dtype=np.int32)
+        rc = self.L.orbm_search_by_projection_fisheye(self.m, C.byref(fs), int(n_left), _p(l2r), _p(r2l), C.byref(qs),
+                                                      C.c_float(self.mfNNratio), int(self.TH_HIGH), _p(F.slot), _p(F.slot_obs), _p(moq), None)
+        self._check(rc, "orbm_search_by_projection_fisheye")
+        if rc < 0:
+            raise OrbError("orbm_search_by_projection_fisheye rc=%d" % rc)
+        mr = moq[1::2].copy()
+        mr[mr >= 0] -= int(n_left)
+        return rc, moq[0::2].copy(), mr
+
+    def SearchByProjectionLastFrameFisheye(self, CurrentFrame, n_left, scale_factors, has_mp, Xw, mp_desc, last_keys, Tcw, Tlw, Trl,
+                                           cam_type, cam_params, th, bMono=False, mb=0.0, mp_obs=None):
+        """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) for a fisheye-stereo current frame --
+        ORBmatcher.cc:2027-2289 complete (incl. the right-camera pass :2189-2256)."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf = a(scale_factors, np.float32)
+        has_mp, Xw, mp_desc = a(has_mp, np.uint8), a(Xw, np.float32), a(mp_desc, np.uint8)
+        last_keys = a(last_keys, KP_DTYPE)
+        Tcw, Tlw, Trl, cam_params = a(Tcw, np.float32), a(Tlw, np.float32), a(Trl, np.float32), a(cam_params, np.float32)
+        obs = None if mp_obs is None else a(mp_obs, np.uint8)
+        fs = CurrentFrame.struct()
+        rc = self.L.orbm_search_by_projection_last_frame_fisheye(self.m, C.byref(fs), int(n_left), _p(sf), len(sf), len(has_mp), _p(has_mp),
+                                                                 _p(Xw), _p(mp_desc), _p(last_keys), _p(obs), _p(Tcw), _p(Tlw), _p(Trl),
+                                                                 int(cam_type), _p(cam_params), C.c_float(mb), C.c_float(th), int(bool(bMono)),
+                                                                 int(self.mbCheckOrientation), _p(CurrentFrame.slot), _p(CurrentFrame.slot_obs))
+        self._check(rc, "orbm_search_by_projection_last_frame_fisheye")
+        if rc < 0:
+            raise OrbError("orbm_search_by_projection_last_frame_fisheye rc=%d" % rc)
         return rc
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,

@@ -24,6 +24,13 @@ struct MatchProblemSet {
   float nnratio; int th_dist; int use_second;
   // in/out
   int32_t *slot; uint8_t *slot_obs; int32_t *match_of_query; int32_t *best_dist; int32_t *nmatches;
+  // fisheye-stereo frames (Nleft != -1), all NULL / 0 otherwise: keypoints [nleft, n) are the right image's; qside[q] = 1
+  // restricts query q to them (0: to the left ones); partner[k] = stereo partner of keypoint k in the other image or -1
+  // (mvLeftToRightMatch / mvRightToLeftMatch); queries come in (left, right) pairs of one map point at (2j, 2j+1):
+  // couple 1 = the right query is dropped when the left one failed the ratio test (ORBmatcher.cc:125 `continue`),
+  // couple 2 = ... when the left one's window was empty (:2126); qany[q] = window of query q non-empty (scan -> resolve);
+  // serial = resolve one query at a time from a fresh list (exact when a partner write can release a claim).
+  int nleft; const uint8_t *qside; const int32_t *partner; int couple; uint8_t *qany; int serial;
   long long *dbg;  // diagnostic builds (-DRESOLVE_STAMPS) only: per-problem cycle sums; never read by the product
 };
 
@@ -89,13 +96,14 @@ struct Key64 {
   }
 };
 
-struct CandMeta { float x, y; uint32_t bits; float ur; };  // bits: octave | gx<<8 | gy<<16 | usable<<24
+struct CandMeta { float x, y; uint32_t bits; float ur; };  // bits: octave | gx<<8 | gy<<16 | usable<<24 | in-grid<<25
 
 __device__ __forceinline__ uint32_t cand_bits(float x, float y, int oct, bool claimed, const MatchProblemSet &M) {
   // Frame::PosInGrid, Frame.cc:815-825
   int gx = (int)roundf((x - M.min_x) * M.inv_w), gy = (int)roundf((y - M.min_y) * M.inv_h);
   bool in = gx >= 0 && gx < 64 && gy >= 0 && gy < 48;
-  return (uint32_t)(oct & 0xff) | ((uint32_t)(gx & 0xff) << 8) | ((uint32_t)(gy & 0xff) << 16) | ((in && !claimed) ? (1u << 24) : 0u);
+  return (uint32_t)(oct & 0xff) | ((uint32_t)(gx & 0xff) << 8) | ((uint32_t)(gy & 0xff) << 16) | ((in && !claimed) ? (1u << 24) : 0u) |
+         (in ? (1u << 25) : 0u);
 }
 __device__ __forceinline__ uint32_t cell_of(uint32_t bits) { return ((bits >> 8) & 0xff) * 48u + ((bits >> 16) & 0xff); }
 
@@ -128,7 +136,9 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
   return ok;
 }
 
-template <typename KT>
+// STEREO: fisheye-stereo problem (image restriction per query, window-non-empty flags); the mono instantiation carries
+// none of that in its inner loop.
+template <typename KT, bool STEREO>
 __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
@@ -154,6 +164,11 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   K top[MATCH_TOPK];
 #pragma unroll
   for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
+  // fisheye-stereo: a query sees only the keypoints of its own image
+  const int nleft = STEREO && M.qside ? M.nleft : n;
+  const bool sideR = STEREO && M.qside && q < nq && M.qside[qo + q] != 0;
+  const bool wantAny = STEREO && M.qany != nullptr;
+  bool any = false;
   // GetFeaturesInArea's level filter (Frame.cc:779, :794-801) as a closed interval; open ends when it is disabled
   const int minlE = w.live && w.checkLevels ? w.minl : -1000;
   const int maxlE = w.live && w.checkLevels && w.maxl >= 0 ? w.maxl : 1000;
@@ -180,9 +195,11 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
         // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
         const int gx = (cm.bits >> 8) & 0xff, gy = (cm.bits >> 16) & 0xff, oct = cm.bits & 0xff;
         int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct);
-        viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
         const int fpass = __float_as_int(fabsf(cm.x - w.u) - w.r) & __float_as_int(fabsf(cm.y - w.v) - w.r);
-        bool ok = (fpass & ~viol) < 0;
+        const bool sok = !STEREO || (base + c >= nleft) == sideR;       // candidate index is uniform: a mask select
+        if (STEREO && wantAny) any = any || (sok && (fpass & ~(viol | ~(int)(cm.bits << 6))) < 0);  // GetFeaturesInArea alone (bit 25 = in grid)
+        viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
+        bool ok = sok && (fpass & ~viol) < 0;
         if (w.stereo) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);   // ORBmatcher.cc:93-98, :2139-2146
         if (ok) {
           const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
     K *o = topk + (qo + q) * MATCH_TOPK;
 #pragma unroll
     for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];
+    if (STEREO && wantAny) M.qany[qo + q] = any ? 1 : 0;
   }
 }
 
@@ -248,7 +266,7 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v)
 
 // Per-lane decision from a query's sorted candidate list (column `lane` of sTk, entry j at sTkLane[64*j]).
 //   vm   bit j: entry j exists;  cm  bit j: entry j is claimed by an earlier query;  oct4: 4-bit octave per entry.
-// Returns accept<<31 | rescan<<30 | bestIdx; *bd_out = distance of the best surviving entry (256 if none).
+// Returns accept<<31 | rescan<<30 | ratioFail<<29 | bestIdx; *bd_out = distance of the best surviving entry (256 if none).
 //
 // Every candidate that is not in the list has key >= tk[TOPK-1], i.e. distance >= lbDist.  An exact rescan is needed
 // only when an unlisted candidate could change the decision:
@@ -270,8 +288,9 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
     else if (found == 1 && M.use_second) rescan = bd <= M.th_dist && (float)bd > M.nnratio * (float)lbDist;
   }
   const bool acc = !rescan && accept_rule(M, found > 0, bd, l1, found > 1, KT::dist(second), l2);
+  const bool ratioFail = !rescan && !acc && found > 0 && bd <= M.th_dist;  // the `continue` of ORBmatcher.cc:125
   *bd_out = bd;
-  return (acc ? 0x80000000u : 0u) | (rescan ? 0x40000000u : 0u) | (found > 0 ? (uint32_t)KT::idx(best) : 0u);
+  return (acc ? 0x80000000u : 0u) | (rescan ? 0x40000000u : 0u) | (ratioFail ? 0x20000000u : 0u) | (found > 0 ? (uint32_t)KT::idx(best) : 0u);
 }
 
 // One workgroup per problem.  All wavefronts build the LDS state; wavefront 0 then resolves the queries, 64 at a time.
@@ -323,6 +342,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   uint32_t *sOwner = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
   int32_t *sSlot = reinterpret_cast<int32_t *>(sOwner + maxn + 1);
   uint16_t *sPerm = reinterpret_cast<uint16_t *>(sSlot + maxn);
+  uint16_t *sPartner = sPerm + ((maxn + 1) & ~1);   // stereo partner of each keypoint, 0xffff = none (only if M.partner)
   int *sFill = sCol + 66;
   for (int i = tid; i < 132; i += 64 * RESOLVE_NW) sCol[i] = 0;
   __syncthreads();
@@ -340,6 +360,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     atomicAdd(&sCol[((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) + 1 : 65], 1);  // histogram shifted by one
   }
   if (tid == 0) sOwner[n] = RESOLVE_FREE;
+  if (M.partner)
+    for (int i = tid; i < n; i += 64 * RESOLVE_NW) { const int32_t pr = M.partner[fo + i]; sPartner[i] = (uint16_t)(pr >= 0 && pr < n ? pr : 0xffff); }
   if (LDSCAND) {
     const uint4 *gd = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
     for (int i = tid; i < 2 * n; i += 64 * RESOLVE_NW) sDesc[i] = gd[i];
@@ -376,6 +398,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     w.cy0 = max(0, (int)floorf((w.v - M.min_y - w.r) * M.inv_h));
     w.cy1 = min(47, (int)ceilf((w.v - M.min_y + w.r) * M.inv_h));
     w.live = (R[1] & 1u) && w.cx0 < 64 && w.cx1 >= 0 && w.cy0 < 48 && w.cy1 >= 0 && w.cx0 <= w.cx1;
+    const int nleft = M.qside ? M.nleft : n;
+    const bool sideR = (R[1] >> 8) & 1u;             // fisheye-stereo: the query sees only the keypoints of its own image
     w.checkLevels = (w.minl > 0) || (w.maxl >= 0);
     w.stereo = M.u_right != nullptr;
     uint32_t q8[8];
@@ -410,6 +434,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     auto consider = [&](const Cand &k) {
       const int gx = (k.bits >> 8) & 0xff, gy = (k.bits >> 16) & 0xff, oct = k.bits & 0xff;
       int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct) | k.c;
+      viol |= ((k.c >= nleft) == sideR) ? 0 : -1;
       viol |= ~(int)(k.bits << 7);                                    // bit 24 = usable (in grid, not claimed)
       const int fpass = __float_as_int(fabsf(k.x - w.u) - w.r) & __float_as_int(fabsf(k.y - w.v) - w.r);
       bool ok = (fpass & ~viol) < 0;
@@ -475,7 +500,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       const int q = base + lane;
       const int cnt = min(64, nq - base);
       // my query: parameters and descriptor stay in registers (they become a refresh request if my list runs out)
-      const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
+      uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
+      if (M.qside && q < nq && M.qside[qo + q]) myfl |= 0x100u;                       // bit 8: right-image query
+      if (M.couple == 2 && (q & 1) && q < nq && !M.qany[qo + q - 1]) myfl &= ~1u;     // :2126, left window empty
       const bool ob = (myfl >> 1) & 1u;
       uint32_t qpar[6] = {0, 0, 0, 0, 0, 0}, qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -510,6 +537,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         const K last = sTk[64 * capm1 + lane];
         truncated = last != KT::NONE;
         lbDist = KT::dist(last);
+        if (!(myfl & 1u)) { vm = 0; truncated = false; }   // dropped query (scan may have listed candidates for it)
       };
       load_list();
       // refresh the lists of the lanes in F, RESOLVE_NW per pass (one wavefront each)
@@ -552,29 +580,43 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       t_chunk += __builtin_readcyclecounter() - tc0;
 #endif
       int s = 0;
-      bool first_round = true;
+      bool first_round = !M.serial;
       while (s < cnt) {
 #ifdef RESOLVE_STAMPS
         long long tr0 = __builtin_readcyclecounter();
 #endif
+        // serial mode: one query at a time, decided from a list made at its turn (sees released claims as well)
+        const int hi = M.serial ? s + 1 : cnt;
+        if (M.serial) refresh(1ull << s);
         int r;
         unsigned long long flagged;
         for (;;) {
-          const bool pend = lane >= s && lane < cnt;
+          const bool pend = lane >= s && lane < hi;
           const bool post = pend && (D >> 31) && ob;
           const int bidx = (int)(D & 0xfffffu);
+          // a claim also takes the keypoint's stereo partner (ORBmatcher.cc:128-132, :199-203)
+          int pidx = n;
+          if (M.partner && post) { const int pr = sPartner[bidx]; pidx = pr == 0xffff ? n : pr; }
           if (post) __hip_atomic_fetch_min(&sOwner[bidx], (uint32_t)(lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (M.partner && pidx != n) __hip_atomic_fetch_min(&sOwner[pidx], (uint32_t)(lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __builtin_amdgcn_wave_barrier();
           uint32_t cm = 0;
 #pragma unroll
           for (int j = 0; j < MATCH_TOPK; j++) cm |= (sOwner[eidx[j]] <= (uint32_t)lane ? 1u : 0u) << j;
-          // withdraw the post - unless the keypoint was committed since my (stale) decision was taken: a committed
+          // withdraw the posts - unless the keypoint was committed since my (stale) decision was taken: a committed
           // claim (0) must survive
           const uint32_t mine = sOwner[post ? bidx : n];
+          uint32_t mineP = 0u;
+          if (M.partner) mineP = sOwner[pidx];
           __builtin_amdgcn_wave_barrier();
           if (post && mine != 0u) sOwner[bidx] = RESOLVE_FREE;
+          if (M.partner && pidx != n && mineP != 0u) sOwner[pidx] = RESOLVE_FREE;
           __builtin_amdgcn_wave_barrier();
-          const uint32_t nD = pend ? decide<KT>(M, sTk + lane, vm, cm, oct4, truncated, lbDist, &my_bd) : D;
+          uint32_t nD = pend ? decide<KT>(M, sTk + lane, vm, cm, oct4, truncated, lbDist, &my_bd) : D;
+          if (M.couple == 1) {  // the right-image query of a map point whose left-image query failed the ratio test is dropped
+            const uint32_t leftD = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)D, 0x111, 0xf, 0xf, true);  // D of lane - 1
+            if (pend && (lane & 1) && ((leftD >> 29) & 1u)) { nD = 0; my_bd = 256; }
+          }
           const bool changed = nD != D;
           D = nD;
           flagged = __ballot(pend && ((D >> 30) & 1u));
@@ -594,7 +636,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
               continue;
             }
           }
-          r = flagged ? (int)__builtin_ctzll(flagged) : cnt;
+          r = flagged ? (int)__builtin_ctzll(flagged) : hi;
           if (!__ballot(changed && lane <= r)) break;
         }
         // commit the settled prefix [s, r)
@@ -604,9 +646,20 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           const int bidx = (int)(D & 0xfffffu);
           nmatches += __popcll(__ballot(acc));
           if (acc) {
+            const int32_t sv = (int32_t)(((uint32_t)q << 1) | (ob ? 1u : 0u));
             if (ob) sOwner[bidx] = 0u;
-            __hip_atomic_fetch_max(&sSlot[bidx], (int32_t)(((uint32_t)q << 1) | (ob ? 1u : 0u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&sSlot[bidx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (M.partner) {
+              const int pr = sPartner[bidx];
+              if (pr != 0xffff) {
+                // the partner's slot is overwritten unconditionally: a holder without observations RELEASES a claim
+                // (only reachable in serial mode; the host selects it whenever such a query exists)
+                sOwner[pr] = ob ? 0u : RESOLVE_FREE;
+                __hip_atomic_fetch_max(&sSlot[pr], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
           }
+          if (M.partner) nmatches += __popcll(__ballot(acc && sPartner[acc ? bidx : 0] != 0xffff));
           if (inpre) { res_idx = acc ? bidx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
         }
         __builtin_amdgcn_wave_barrier();
@@ -614,7 +667,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         t_round += __builtin_readcyclecounter() - tr0;
 #endif
         s = r;
-        if (r < cnt) refresh(flagged);  // lane r is now first in line: with its fresh list it decides in the next round
+        if (r < hi) refresh(flagged);   // lane r is now first in line: with its fresh list it decides in the next round
       }
       if (q < nq) {
         if (M.match_of_query) M.match_of_query[qo + q] = res_idx;

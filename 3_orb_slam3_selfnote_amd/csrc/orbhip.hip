@@ -604,6 +604,10 @@ struct orbm_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
+  DevBuf d_partner, d_qside, d_qany;
+  // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
+  // orbm_search_by_projection_batch_device): device pointers
+  struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; } ext;
   bool profiling = false;
   hipEvent_t ev[3] = {};
   bool ev_ok = false, ms_valid = false;
@@ -640,7 +644,7 @@ void orbm_destroy(orbm_t *m) {
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
-                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk};
+                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany};
   for (DevBuf *b : bufs) b->release();
   if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); (void)hipEventDestroy(m->ev[2]); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -786,6 +790,9 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
 #ifdef RESOLVE_STAMPS
   M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
 #endif
+  M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
+  M.serial = m->ext.serial; M.qany = m->ext.qany;
+  m->ext = {};
   const int maxn = d_frame_n ? frame_stride : f->n;
   const int maxq = d_query_n ? query_stride : q->nq;
   if (maxn > ORBM_MAX_KEYPOINTS) { m->err = "more than 15360 keypoints per frame not supported by the search kernels"; return ORBX_E_ARG; }
@@ -802,7 +809,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16); see k_match_resolve
-  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + 2);
+  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
   const size_t big = small + 48 * (size_t)maxn;
   const bool ldscand = big <= 150 * 1024;
   const size_t lds = ldscand ? big : small;
@@ -812,7 +819,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (lds > 48 * 1024)                                                                                                  \
       MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL(k_match_scan<KT>, sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                           \
+    if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, true>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);       \
+    else hipLaunchKernelGGL((k_match_scan<KT, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
     if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
     hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);     \
   } while (0)
@@ -824,8 +832,19 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   return 0;
 }
 
+// host-pointer fisheye-stereo options of one search (see MatchProblemSet)
+struct StereoExt { int nleft; const int32_t *partner; const uint8_t *qside; int couple; int serial; };
+
+static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist, int use_second,
+                       int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist, const StereoExt *ext);
+
 int orbm_search_by_projection(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist,
                               int use_second, int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist) {
+  return search_host(m, f, q, nnratio, th_dist, use_second, slot, slot_obs, match_of_query, best_dist, nullptr);
+}
+
+static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist, int use_second,
+                       int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist, const StereoExt *ext) {
   if (!m || !f || !q || !slot || !slot_obs) return ORBX_E_ARG;
   const int n = f->n, nq = q->nq;
   if (n < 0 || nq < 0) return ORBX_E_ARG;
@@ -853,6 +872,18 @@ int orbm_search_by_projection(orbm_t *m, const orbm_frame_t *f, const orbm_queri
   if (q->flags) UP(m->d_qfl, q->flags, (size_t)nq);
   UP(m->d_slot, slot, sizeof(int32_t) * (size_t)n);
   UP(m->d_sobs, slot_obs, (size_t)n);
+  m->ext = {};
+  if (ext) {
+    if (ext->partner) UP(m->d_partner, ext->partner, sizeof(int32_t) * (size_t)n);
+    if (ext->qside) UP(m->d_qside, ext->qside, (size_t)nq);
+    if (ext->couple == 2) MCHECK(m, m->d_qany.reserve((size_t)nq));
+    m->ext.nleft = ext->nleft;
+    m->ext.partner = ext->partner ? (const int32_t *)m->d_partner.p : nullptr;
+    m->ext.qside = ext->qside ? (const uint8_t *)m->d_qside.p : nullptr;
+    m->ext.couple = ext->couple;
+    m->ext.serial = ext->serial;
+    m->ext.qany = ext->couple == 2 ? (uint8_t *)m->d_qany.p : nullptr;
+  }
 #undef UP
   MCHECK(m, m->d_moq.reserve(sizeof(int32_t) * (size_t)nq));
   MCHECK(m, m->d_bd.reserve(sizeof(int32_t) * (size_t)nq));
@@ -959,6 +990,105 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
     for (int idx : rotHist[i]) { slot[idx] = -1; slot_obs[idx] = 0; nmatches--; }
   }
   return nmatches;
+}
+
+static int prune_by_rotation(int nq, const int32_t *moq, const float *query_angle, const orbx_keypoint_t *keys, int32_t *slot,
+                             uint8_t *slot_obs, int nmatches);
+
+// ---- fisheye-stereo frames (Nleft != -1) -------------------------------------------------------------------------
+// One problem over the concatenated keypoints [left ; right] with two queries per map point (even = left image,
+// odd = right image): the device core handles the image restriction, the stereo-partner writes and the pair coupling.
+static int build_partner(int n, int n_left, const int32_t *l2r, const int32_t *r2l, std::vector<int32_t> &partner) {
+  partner.assign((size_t)n, -1);
+  bool any = false;
+  for (int i = 0; i < n_left; i++)
+    if (l2r && l2r[i] >= 0) { if (n_left + l2r[i] >= n) return ORBX_E_ARG; partner[i] = n_left + l2r[i]; any = true; }
+  for (int j = 0; j < n - n_left; j++)
+    if (r2l && r2l[j] >= 0) { if (r2l[j] >= n_left) return ORBX_E_ARG; partner[n_left + j] = r2l[j]; any = true; }
+  return any ? 1 : 0;
+}
+
+int orbm_search_by_projection_fisheye(orbm_t *m, const orbm_frame_t *f, int n_left, const int32_t *left_to_right,
+                                      const int32_t *right_to_left, const orbm_queries_t *q, float nnratio, int th_dist,
+                                      int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist) {
+  if (!m || !f || !q || n_left < 0 || n_left > f->n || (q->nq & 1)) return ORBX_E_ARG;
+  std::vector<int32_t> partner;
+  const int anyp = build_partner(f->n, n_left, left_to_right, right_to_left, partner);
+  if (anyp < 0) return anyp;
+  std::vector<uint8_t> side((size_t)q->nq);
+  bool release = false;  // a taking query without observations can release a claim through a partner write
+  for (int i = 0; i < q->nq; i++) {
+    side[i] = (uint8_t)(i & 1);
+    const uint8_t fl = q->flags ? q->flags[i] : (uint8_t)3;
+    if ((fl & 1) && !(fl & 2)) release = true;
+  }
+  StereoExt ext{n_left, anyp ? partner.data() : nullptr, side.data(), 1, (anyp && release) ? 1 : 0};
+  return search_host(m, f, q, nnratio, th_dist, 1, slot, slot_obs, match_of_query, best_dist, &ext);
+}
+
+int orbm_search_by_projection_last_frame_fisheye(orbm_t *m, const orbm_frame_t *cur, int n_left, const float *sf, int nlevels,
+                                                 int nLast, const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
+                                                 const orbx_keypoint_t *last_keys, const uint8_t *obs, const float *Tcw,
+                                                 const float *Tlw, const float *Trl, int cam_type, const float *cam_params,
+                                                 float mb, float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs) {
+  if (!m || !cur || !sf || nLast < 0 || !Tcw || !Tlw || !Trl || !cam_params || !slot || !slot_obs) return ORBX_E_ARG;
+  if (n_left < 0 || n_left > cur->n) return ORBX_E_ARG;
+  if (nLast > 0 && (!has_mp || !Xw || !mpdesc || !last_keys)) return ORBX_E_ARG;
+  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]}, tlw[3] = {Tlw[3], Tlw[7], Tlw[11]}, trl[3] = {Trl[3], Trl[7], Trl[11]};
+  float twc[3], tlc[3];
+  for (int i = 0; i < 3; i++) {  // twc = -Rcw.t()*tcw, :2041
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)tcw[k];
+    twc[i] = (float)(s * -1.0);
+  }
+  mat3_mul_add(Tlw, twc, tlw, tlc);
+  const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;
+  const int nq = 2 * nLast;
+  std::vector<float> u(nq, 0.f), v(nq, 0.f), rad(nq, 0.f), qangle(nq, 0.f);
+  std::vector<int32_t> minl(nq, -1), maxl(nq, -1), moq(nq, -1);
+  std::vector<uint8_t> flags(nq, 0), side(nq), qd((size_t)nq * 32);
+  for (int i = 0; i < nLast; i++) {
+    side[2 * i] = 0; side[2 * i + 1] = 1;
+    memcpy(&qd[(size_t)(2 * i) * 32], mpdesc + (size_t)i * 32, 32);
+    memcpy(&qd[(size_t)(2 * i + 1) * 32], mpdesc + (size_t)i * 32, 32);
+    qangle[2 * i] = qangle[2 * i + 1] = last_keys[i].angle;
+    if (!has_mp[i]) continue;
+    float x3Dc[3], x3Dr[3];
+    mat3_mul_add(Tcw, Xw + 3 * i, tcw, x3Dc);                  // :2072
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);        // :2076
+    if (invzc < 0) continue;
+    float ux, vy;
+    orbm_project(cam_type, cam_params, x3Dc[0], x3Dc[1], x3Dc[2], &ux, &vy);
+    if (ux < cur->min_x || ux > cur->max_x) continue;          // :2094-2097
+    if (vy < cur->min_y || vy > cur->max_y) continue;
+    const int nLastOctave = last_keys[i].octave;
+    if (nLastOctave < 0 || nLastOctave >= nlevels) return ORBX_E_ARG;
+    mat3_mul_add(Trl, x3Dc, trl, x3Dr);                        // :2190
+    float uxr, vyr;
+    orbm_project(cam_type, cam_params, x3Dr[0], x3Dr[1], x3Dr[2], &uxr, &vyr);
+    const uint8_t fl = (uint8_t)(1u | ((obs ? (obs[i] & 1u) : 1u) << 1));
+    for (int h = 0; h < 2; h++) {
+      const int j = 2 * i + h;
+      u[j] = h ? uxr : ux; v[j] = h ? vyr : vy;
+      rad[j] = th * sf[nLastOctave];                           // :2105, :2197
+      if (bForward) { minl[j] = nLastOctave; maxl[j] = -1; }   // :2113-2118, :2201-2206
+      else if (bBackward) { minl[j] = 0; maxl[j] = nLastOctave; }
+      else { minl[j] = nLastOctave - 1; maxl[j] = nLastOctave + 1; }
+      flags[j] = fl;
+    }
+  }
+  orbm_queries_t q;
+  q.nq = nq; q.descriptors = qd.data(); q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = nullptr; q.flags = flags.data();
+  orbm_frame_t f = *cur;
+  f.u_right = nullptr;  // Nleft != -1: no mvuRight test (:2139)
+  StereoExt ext{n_left, nullptr, side.data(), 2, 0};
+  int nmatches = search_host(m, &f, &q, 0.f, ORBM_TH_HIGH, 0, slot, slot_obs, moq.data(), nullptr, &ext);
+  if (nmatches < 0) return nmatches;
+  for (int j = 0; j < nq; j++)  // the device stored query indices; the caller's ids are last-frame indices (in order: last writer wins)
+    if (moq[j] >= 0) slot[moq[j]] = j >> 1;
+  if (!checkOri) return nmatches;
+  return prune_by_rotation(nq, moq.data(), qangle.data(), cur->keys_un, slot, slot_obs, nmatches);
 }
 
 // Rotation-consistency pruning shared by the projection searches (e.g. ORBmatcher.cc:2177-2185 + :2263-2286).

@@ -193,6 +193,29 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
                                          const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
                                          float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* The same two members for a fisheye-stereo frame (Frame::Nleft != -1): ORBmatcher.cc:44-214 with its second half
+ * (:145-211, right camera) and ORBmatcher.cc:2027-2289 with its extra pass (:2189-2256).
+ * frame: n = Nleft + Nright; keys_un = mvKeys followed by mvKeysRight (raw keypoints: GetFeaturesInArea reads mvKeys /
+ * mvKeysRight when Nleft != -1, Frame.cc:791-793), descriptors = mDescriptors (vconcat of both images, Frame.cc
+ * fisheye ctor), u_right = NULL; slot / slot_obs have n entries (F.mvpMapPoints; right keypoint j is entry Nleft + j).
+ * left_to_right[Nleft] / right_to_left[Nright] = mvLeftToRightMatch / mvRightToLeftMatch (index in the other image
+ * or -1; NULL = none): an accepted match also writes the partner's slot (:128-132, :199-203).
+ * Queries: TWO per map point, query 2j = left image (mTrackProjX/Y, mnTrackScaleLevel, mbTrackInView), query 2j+1 =
+ * right image (mTrackProjXR/YR, mnTrackScaleLevelR, mbTrackInViewR && level != -1); radius as in
+ * orbm_queries_t (the right half does not multiply by th, :148).  The reference's `continue` at :125 (left ratio
+ * test failed => right half skipped) is applied inside.  Returns nmatches including the partner increments. */
+int orbm_search_by_projection_fisheye(orbm_t *m, const orbm_frame_t *frame, int n_left, const int32_t *left_to_right,
+                                      const int32_t *right_to_left, const orbm_queries_t *q, float nnratio, int th_dist,
+                                      int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist);
+/* Trl = CurrentFrame.mTrl (row-major 3x4 or 4x4, row stride 4).  slot values are last-frame indices i.  The right
+ * pass of a map point is skipped when its left window is empty (:2126). */
+int orbm_search_by_projection_last_frame_fisheye(orbm_t *m, const orbm_frame_t *cur, int n_left, const float *scale_factors,
+                                                 int nlevels, int nLast, const uint8_t *has_mp, const float *Xw,
+                                                 const uint8_t *mpdesc, const orbx_keypoint_t *last_keys, const uint8_t *obs,
+                                                 const float *Tcw, const float *Tlw, const float *Trl, int cam_type,
+                                                 const float *cam_params, float mb, float th, int bMono, int checkOri,
+                                                 int32_t *slot, uint8_t *slot_obs);
+
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
  *                                    const float th, const int ORBdist)                       (ORBmatcher.cc:2291-2413)
  * flattened, host pointers.  i in [0, nKF): valid[i] = pMP && !pMP->isBad() && !sAlreadyFound.count(pMP);

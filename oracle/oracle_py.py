@@ -75,6 +75,9 @@ def lib():
         _lib.orc_search_by_projection_win.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
         _lib.orc_search_by_projection_ff.argtypes = ([C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p] +
                                                      [C.c_float] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        _lib.orc_search_by_projection_mp_fisheye.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 12 + [C.c_float, C.c_float] + [C.c_void_p] * 4)
+        _lib.orc_search_by_projection_ff_fisheye.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p] +
+                                                             [C.c_float] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         _lib.orc_frame_init.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p, C.c_int]
     return _lib
 
@@ -268,6 +271,44 @@ class OracleFrame:
                                                   _p(last_angle), _p(qobs), _p(Tcw), _p(Tlw), int(cam_type), _p(cam_params),
                                                   C.c_float(mb), C.c_float(mbf), C.c_float(th), int(mono), int(check_ori),
                                                   _p(self.slot), _p(self.slot_obs))
+
+
+class OracleFisheyeFrame:
+    """A fisheye-stereo Frame (Nleft != -1): left grid over mvKeys, right grid over mvKeysRight, one mvpMapPoints array."""
+
+    def __init__(self, left, right):
+        self.L = lib()
+        self.left, self.right = left, right            # OracleFrame each (same bounds)
+        self.n_left = left.N
+        self.slot = np.full(left.N + right.N, -1, dtype=np.int32)
+        self.slot_obs = np.zeros(left.N + right.N, dtype=np.uint8)
+
+    def search_by_projection_mp(self, l2r, r2l, in_view, in_view_r, qdesc, projX, projY, viewCos, level, projXR, projYR, viewCosR,
+                                levelR, th, nnratio, qobs=None):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        nmp = len(level)
+        ml, mr = np.full(nmp, -1, np.int32), np.full(nmp, -1, np.int32)
+        l2r, r2l = a(l2r, np.int32), a(r2l, np.int32)
+        args = [a(in_view, np.uint8), a(in_view_r, np.uint8), a(qdesc, np.uint8), a(projX, np.float32), a(projY, np.float32),
+                a(viewCos, np.float32), a(level, np.int32), a(projXR, np.float32), a(projYR, np.float32), a(viewCosR, np.float32),
+                a(levelR, np.int32), a(qobs, np.uint8) if qobs is not None else np.ones(nmp, np.uint8)]
+        n = self.L.orc_search_by_projection_mp_fisheye(C.byref(self.left.f), C.byref(self.right.f), _p(l2r), _p(r2l), nmp,
+                                                       *[_p(x) for x in args], C.c_float(th), C.c_float(nnratio),
+                                                       _p(self.slot), _p(self.slot_obs), _p(ml), _p(mr))
+        return n, ml, mr
+
+    def search_by_projection_ff(self, has_mp, Xw, mpdesc, last_octave, last_angle, Tcw, Tlw, Trl, cam_type, cam_params, th,
+                                mono=False, check_ori=True, mb=0.0, qobs=None):
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        n_last = len(has_mp)
+        has_mp, Xw, mpdesc = a(has_mp, np.uint8), a(Xw, np.float32), a(mpdesc, np.uint8)
+        last_octave, last_angle = a(last_octave, np.int32), a(last_angle, np.float32)
+        Tcw, Tlw, Trl, cam_params = a(Tcw, np.float32), a(Tlw, np.float32), a(Trl, np.float32), a(cam_params, np.float32)
+        qobs = a(qobs, np.uint8) if qobs is not None else np.ones(n_last, np.uint8)
+        return self.L.orc_search_by_projection_ff_fisheye(C.byref(self.left.f), C.byref(self.right.f), n_last, _p(has_mp), _p(Xw),
+                                                          _p(mpdesc), _p(last_octave), _p(last_angle), _p(qobs), _p(Tcw), _p(Tlw),
+                                                          _p(Trl), int(cam_type), _p(cam_params), C.c_float(mb), C.c_float(th),
+                                                          int(mono), int(check_ori), _p(self.slot), _p(self.slot_obs))
 
 
 class KeyFrame(C.Structure):

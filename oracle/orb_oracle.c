@@ -1066,6 +1066,232 @@ int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* M2 with a fisheye-stereo frame (Nleft != -1), ORBmatcher.cc:44-214 complete: left half on    */
+/* mGrid / mvKeys, right half (:145-211) on mGridRight / mvKeysRight, the partner writes through */
+/* mvLeftToRightMatch / mvRightToLeftMatch (:128-132, :199-203) and the `continue` of :125 that  */
+/* also skips the right half of the same map point.  slot / slot_obs hold Nleft + Nright entries */
+/* (F.mvpMapPoints); right keypoint j is entry Nleft + j.                                        */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_projection_mp_fisheye(orc_frame *fl, orc_frame *fr, const int32_t *leftToRight,
+                                        const int32_t *rightToLeft, int nmp, const uint8_t *in_view,
+                                        const uint8_t *in_view_r, const uint8_t *qdesc, const float *projX,
+                                        const float *projY, const float *viewCos, const int32_t *level,
+                                        const float *projXR, const float *projYR, const float *viewCosR,
+                                        const int32_t *levelR, const uint8_t *qobs, float th, float nnratio,
+                                        int32_t *slot, uint8_t *slot_obs, int32_t *match_left, int32_t *match_right) {
+  int nmatches = 0;
+  const int Nleft = fl->N;
+  const int bFactor = ((double)th != 1.0);
+  const int cap = (fl->N > fr->N ? fl->N : fr->N) + 1;
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+  for (int q = 0; q < nmp; q++) {
+    if (match_left) match_left[q] = -1;
+    if (match_right) match_right[q] = -1;
+    if (!in_view[q] && !in_view_r[q]) continue;
+    const uint8_t ob = qobs ? qobs[q] : 1;
+    const uint8_t *MPdescriptor = qdesc + 32 * (size_t)q;
+    if (in_view[q]) {
+      const int nPredictedLevel = level[q];
+      float r = orc_radius_by_viewing_cos(viewCos[q]);
+      if (bFactor) r *= th;
+      int nv = orc_get_features_in_area(fl, projX[q], projY[q], r * fl->mvScaleFactors[nPredictedLevel],
+                                        nPredictedLevel - 1, nPredictedLevel, vIndices);
+      if (nv != 0) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nv; k++) {
+          const int idx = vIndices[k];
+          if (slot[idx] >= 0)
+            if (slot_obs[idx]) continue;
+          /* F.Nleft != -1: no mvuRight test (:93) */
+          const int dist = orc_descriptor_distance(MPdescriptor, fl->desc + 32 * (size_t)idx);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = fl->octave[idx];
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = fl->octave[idx];
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= 100 /* TH_HIGH */) {
+          if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue; /* :125, skips the right half too */
+          slot[bestIdx] = q;
+          slot_obs[bestIdx] = ob;
+          if (match_left) match_left[q] = bestIdx;
+          if (leftToRight[bestIdx] != -1) { /* :128-132, unconditional overwrite of the partner's slot */
+            slot[leftToRight[bestIdx] + Nleft] = q;
+            slot_obs[leftToRight[bestIdx] + Nleft] = ob;
+            nmatches++;
+          }
+          nmatches++;
+        }
+      }
+    }
+    if (in_view_r[q]) {
+      const int nPredictedLevel = levelR[q];
+      if (nPredictedLevel != -1) {
+        float r = orc_radius_by_viewing_cos(viewCosR[q]); /* :148, not multiplied by th */
+        int nv = orc_get_features_in_area(fr, projXR[q], projYR[q], r * fr->mvScaleFactors[nPredictedLevel],
+                                          nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (nv == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nv; k++) {
+          const int idx = vIndices[k];
+          if (slot[idx + Nleft] >= 0)
+            if (slot_obs[idx + Nleft]) continue;
+          const int dist = orc_descriptor_distance(MPdescriptor, fr->desc + 32 * (size_t)idx);
+          if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = fr->octave[idx];
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = fr->octave[idx];
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= 100 /* TH_HIGH */) {
+          if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+          if (rightToLeft[bestIdx] != -1) { /* :199-203 */
+            slot[rightToLeft[bestIdx]] = q;
+            slot_obs[rightToLeft[bestIdx]] = ob;
+            nmatches++;
+          }
+          slot[bestIdx + Nleft] = q;
+          slot_obs[bestIdx + Nleft] = ob;
+          if (match_right) match_right[q] = bestIdx;
+          nmatches++;
+        }
+      }
+    }
+  }
+  free(vIndices);
+  return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* M3 with a fisheye-stereo current frame, ORBmatcher.cc:2027-2289 complete: the left search and  */
+/* the extra right-camera pass (:2189-2256, x3Dr = Rrl * x3Dc + trl projected with the same      */
+/* camera); `if(vIndices2.empty()) continue;` (:2126) of the left search skips the right pass.    */
+/* curAngle[]: angles of mvKeys (left, Nleft) followed by mvKeysRight (right).                    */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast, const uint8_t *has_mp, const float *Xw,
+                                        const uint8_t *mpdesc, const int32_t *lastOctave, const float *lastAngle,
+                                        const uint8_t *qobs, const float *Tcw, const float *Tlw, const float *Trl,
+                                        int camType, const float *camParams, float mb, float th, int bMono, int checkOri,
+                                        int32_t *slot, uint8_t *slot_obs) {
+  int nmatches = 0;
+  const int HISTO_LENGTH = 30;
+  const int Nleft = cl->N;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(2 * nLast + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+  float tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+  float trl[3] = {Trl[3], Trl[7], Trl[11]};
+  float twc[3];
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)tcw[k];
+    twc[i] = (float)(s * -1.0);
+  }
+  float tlc[3];
+  mat3_mul_add(Tlw, 4, twc, tlw, tlc);
+  const int bForward = tlc[2] > mb && !bMono;
+  const int bBackward = -tlc[2] > mb && !bMono;
+  const int cap = (cl->N > cr->N ? cl->N : cr->N) + 1;
+  int32_t *vIndices2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+  for (int i = 0; i < nLast; i++) {
+    if (!has_mp[i]) continue;
+    float x3Dc[3];
+    mat3_mul_add(Tcw, 4, Xw + 3 * i, tcw, x3Dc);
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (invzc < 0) continue;
+    float uvx, uvy;
+    orc_project(camType, camParams, x3Dc[0], x3Dc[1], x3Dc[2], &uvx, &uvy);
+    if (uvx < cl->mnMinX || uvx > cl->mnMaxX) continue;
+    if (uvy < cl->mnMinY || uvy > cl->mnMaxY) continue;
+    const int nLastOctave = lastOctave[i];
+    const float radius = th * cl->mvScaleFactors[nLastOctave];
+    const uint8_t ob = qobs ? qobs[i] : 1;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)i;
+    int nv;
+    if (bForward) nv = orc_get_features_in_area(cl, uvx, uvy, radius, nLastOctave, -1, vIndices2);
+    else if (bBackward) nv = orc_get_features_in_area(cl, uvx, uvy, radius, 0, nLastOctave, vIndices2);
+    else nv = orc_get_features_in_area(cl, uvx, uvy, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+    if (nv == 0) continue; /* :2126 - the right pass of this map point is skipped as well */
+    {
+      int bestDist = 256, bestIdx2 = -1;
+      for (int k = 0; k < nv; k++) {
+        const int i2 = vIndices2[k];
+        if (slot[i2] >= 0)
+          if (slot_obs[i2]) continue;
+        /* CurrentFrame.Nleft != -1: no mvuRight test (:2139) */
+        const int dist = orc_descriptor_distance(dMP, cl->desc + 32 * (size_t)i2);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+      if (bestDist <= 100 /* TH_HIGH */) {
+        slot[bestIdx2] = i;
+        slot_obs[bestIdx2] = ob;
+        nmatches++;
+        if (checkOri) {
+          float rot = lastAngle[i] - cl->angle[bestIdx2];
+          if ((double)rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin][rotN[bin]++] = bestIdx2;
+        }
+      }
+    }
+    {
+      float x3Dr[3];
+      mat3_mul_add(Trl, 4, x3Dc, trl, x3Dr); /* :2190 */
+      float uvxr, uvyr;
+      orc_project(camType, camParams, x3Dr[0], x3Dr[1], x3Dr[2], &uvxr, &uvyr);
+      if (bForward) nv = orc_get_features_in_area(cr, uvxr, uvyr, radius, nLastOctave, -1, vIndices2);
+      else if (bBackward) nv = orc_get_features_in_area(cr, uvxr, uvyr, radius, 0, nLastOctave, vIndices2);
+      else nv = orc_get_features_in_area(cr, uvxr, uvyr, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+      int bestDist = 256, bestIdx2 = -1;
+      for (int k = 0; k < nv; k++) {
+        const int i2 = vIndices2[k];
+        if (slot[i2 + Nleft] >= 0)
+          if (slot_obs[i2 + Nleft]) continue;
+        const int dist = orc_descriptor_distance(dMP, cr->desc + 32 * (size_t)i2);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+      if (bestDist <= 100 /* TH_HIGH */) {
+        slot[bestIdx2 + Nleft] = i;
+        slot_obs[bestIdx2 + Nleft] = ob;
+        nmatches++;
+        if (checkOri) {
+          float rot = lastAngle[i] - cr->angle[bestIdx2];
+          if ((double)rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin][rotN[bin]++] = bestIdx2 + Nleft;
+        }
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (int j = 0; j < rotN[i]; j++) {
+          slot[rotHist[i][j]] = -1;
+          slot_obs[rotHist[i][j]] = 0;
+          nmatches--;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  free(vIndices2);
+  return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M6, ORBmatcher.cc:981-1222 + Pinhole::epipolarConstrain, Pinhole.cpp:143-165                 */
 /* cv::Mat algebra restated per SURVEY.md A.8 [OPENCV-UNVERIFIED]:                              */
 /*  - 3x3 * 3x3 / 3x3 * 3x1 products without flags: float dot products (a0*b0+a1*b1+a2*b2 in    */

@@ -154,6 +154,21 @@ int orc_search_by_projection_ff(orc_frame *cur, int nLast, const uint8_t *has_mp
                                 const float *Tcw, const float *Tlw, int camType, const float *camParams, float mb, float mbf,
                                 float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
 
+/* M2 / M3 with a fisheye-stereo frame (Nleft != -1): left grid over mvKeys, right grid over mvKeysRight, one slot
+ * array of Nleft + Nright entries (F.mvpMapPoints).  ORBmatcher.cc:44-214 resp. :2027-2289 complete. */
+int orc_search_by_projection_mp_fisheye(orc_frame *fl, orc_frame *fr, const int32_t *leftToRight,
+                                        const int32_t *rightToLeft, int nmp, const uint8_t *in_view,
+                                        const uint8_t *in_view_r, const uint8_t *qdesc, const float *projX,
+                                        const float *projY, const float *viewCos, const int32_t *level,
+                                        const float *projXR, const float *projYR, const float *viewCosR,
+                                        const int32_t *levelR, const uint8_t *qobs, float th, float nnratio,
+                                        int32_t *slot, uint8_t *slot_obs, int32_t *match_left, int32_t *match_right);
+int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast, const uint8_t *has_mp, const float *Xw,
+                                        const uint8_t *mpdesc, const int32_t *lastOctave, const float *lastAngle,
+                                        const uint8_t *qobs, const float *Tcw, const float *Tlw, const float *Trl,
+                                        int camType, const float *camParams, float mb, float th, int bMono, int checkOri,
+                                        int32_t *slot, uint8_t *slot_obs);
+
 /* The slice of KeyFrame that SearchForTriangulation reads. */
 typedef struct {
   int N;

@@ -277,3 +277,99 @@ def test_search_by_projection_sim3_m5(pkg, oracle, synth, matcher, ratio):
     n_ref = oracle.search_by_projection_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 8, ratio)
     assert n_gpu == n_ref and n_ref > 100
     assert np.array_equal(KF.slot, OKF.slot) and np.array_equal(KF.slot_obs, OKF.slot_obs)
+
+
+def _fisheye_scene(pkg, oracle, synth, seed):
+    """Map points = keypoints of frame 0; fisheye-stereo current frame: left image = frame 1, right image = frame 2."""
+    frames, offs = synth.make_stream(seed, 3)
+    o = oracle.OracleExtractor(**EUROC)
+    (_, k0, d0), (_, kl, dl), (_, kr, dr) = o.extract(frames[0]), o.extract(frames[1]), o.extract(frames[2])
+    sf = o.scale_factors
+    rng = np.random.default_rng(seed)
+    nl, nr = len(kl), len(kr)
+    l2r = np.full(nl, -1, np.int32)
+    r2l = np.full(nr, -1, np.int32)
+    picks_l = rng.permutation(nl)[: int(0.45 * min(nl, nr))]
+    picks_r = rng.permutation(nr)[: len(picks_l)]
+    l2r[picks_l] = picks_r                                           # mvLeftToRightMatch / mvRightToLeftMatch
+    r2l[picks_r] = picks_l
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    keys = np.concatenate([kl, kr])
+    desc = np.concatenate([dl, dr])
+    F = pkg.FrameView(keys, desc, bounds)
+    OFl = oracle.OracleFrame(kl["x"], kl["y"], kl["octave"], kl["angle"], dl, bounds, sf)
+    OFr = oracle.OracleFrame(kr["x"], kr["y"], kr["octave"], kr["angle"], dr, bounds, sf)
+    OF = oracle.OracleFisheyeFrame(OFl, OFr)
+    return k0, d0, offs, sf, F, OF, l2r, r2l, nl, rng
+
+
+@pytest.mark.parametrize("all_obs", [True, False])
+def test_search_by_projection_m2_fisheye(pkg, oracle, synth, matcher, all_obs):
+    """ORBmatcher.cc:44-214 complete for Nleft != -1: left + right halves, stereo-partner slot writes, the `continue` that
+    drops the right half, and (all_obs=False) map points without observations whose partner writes release claims."""
+    k0, d0, offs, sf, F, OF, l2r, r2l, nl, rng = _fisheye_scene(pkg, oracle, synth, 3500)
+    nmp = len(k0)
+    projX = (k0["x"] + np.float32(offs[0][0] - offs[1][0])).astype(np.float32)
+    projY = (k0["y"] + np.float32(offs[0][1] - offs[1][1])).astype(np.float32)
+    projXR = (k0["x"] + np.float32(offs[0][0] - offs[2][0])).astype(np.float32)
+    projYR = (k0["y"] + np.float32(offs[0][1] - offs[2][1])).astype(np.float32)
+    viewCos = rng.choice(np.array([0.9, 0.9985, 1.0], dtype=np.float32), nmp)
+    viewCosR = rng.choice(np.array([0.9, 0.9985, 1.0], dtype=np.float32), nmp)
+    level = k0["octave"].astype(np.int32)
+    levelR = np.where(rng.random(nmp) < 0.05, -1, level).astype(np.int32)
+    in_view = (rng.random(nmp) < 0.9).astype(np.uint8)
+    in_view_r = (rng.random(nmp) < 0.85).astype(np.uint8)
+    obs = np.ones(nmp, np.uint8) if all_obs else (rng.random(nmp) < 0.6).astype(np.uint8)
+    pre = rng.permutation(F.N)[:60]                                   # keypoints already holding a map point
+    pre_obs = (rng.random(60) < 0.5).astype(np.uint8)
+    total = 0
+    for th in (1.0, 4.0):
+        F.slot[:] = -1; F.slot_obs[:] = 0; OF.slot[:] = -1; OF.slot_obs[:] = 0
+        F.slot[pre] = 2 * (nmp + 7); OF.slot[pre] = nmp + 7          # device slots hold QUERY ids (2 per map point)
+        F.slot_obs[pre] = pre_obs; OF.slot_obs[pre] = pre_obs
+        n_gpu, ml_gpu, mr_gpu = matcher.SearchByProjectionFisheye(F, nl, l2r, r2l, d0, sf, th, in_view, projX, projY, viewCos, level,
+                                                                  in_view_r, projXR, projYR, viewCosR, levelR, mp_obs=obs)
+        n_ref, ml_ref, mr_ref = OF.search_by_projection_mp(l2r, r2l, in_view, in_view_r, d0, projX, projY, viewCos, level, projXR, projYR,
+                                                           viewCosR, levelR, th, 0.8, qobs=obs)
+        assert n_gpu == n_ref and n_ref > 200
+        assert np.array_equal(ml_gpu, ml_ref) and np.array_equal(mr_gpu, mr_ref)
+        holder = np.where(F.slot >= 0, F.slot >> 1, -1)
+        assert np.array_equal(holder, OF.slot)
+        assert np.array_equal(F.slot_obs[F.slot >= 0], OF.slot_obs[OF.slot >= 0])
+        total += int((mr_ref >= 0).sum())
+    assert total > 100
+
+
+@pytest.mark.parametrize("cam,tz", [(1, 0.0), (1, -0.3), (0, 0.3)])
+def test_search_by_projection_last_frame_m3_fisheye(pkg, oracle, synth, matcher, cam, tz):
+    """ORBmatcher.cc:2027-2289 complete for a fisheye-stereo current frame: left search + right-camera pass through Trl,
+    forward / backward / neutral level windows, rotation-histogram pruning over both images."""
+    k0, d0, offs, sf, F, OF, l2r, r2l, nl, rng = _fisheye_scene(pkg, oracle, synth, 3600 + cam)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    n0 = len(k0)
+    z = np.float32(5.0)
+    Xw = np.stack([(k0["x"] - np.float32(cx)) / np.float32(fx) * z, (k0["y"] - np.float32(cy)) / np.float32(fy) * z,
+                   np.full(n0, z, np.float32)], axis=1).astype(np.float32)
+    Xw[rng.random(n0) < 0.03, 2] = -1.0
+    dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, 3] = [dx * z / fx, dy * z / fy, tz]
+    Tlw = np.eye(4, dtype=np.float32)
+    Trl = np.eye(4, dtype=np.float32)                                 # right camera: shift that maps frame 1 onto frame 2
+    Trl[:3, 3] = [(offs[1][0] - offs[2][0]) * z / fx, (offs[1][1] - offs[2][1]) * z / fy, 0.0]
+    has_mp = (rng.random(n0) < 0.8).astype(np.uint8)
+    obs = (rng.random(n0) < 0.9).astype(np.uint8)
+    if cam == 0:
+        params = np.array([fx, fy, cx, cy], np.float32)
+    else:
+        params = np.array([190.978477 * 2, 190.973307 * 2, 376.0, 240.0, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736], np.float32)
+    total = 0
+    for th in (7.0, 14.0):
+        F.slot[:] = -1; F.slot_obs[:] = 0; OF.slot[:] = -1; OF.slot_obs[:] = 0
+        n_gpu = matcher.SearchByProjectionLastFrameFisheye(F, nl, sf, has_mp, Xw, d0, k0, Tcw, Tlw, Trl, cam, params, th, bMono=False, mb=0.11, mp_obs=obs)
+        n_ref = OF.search_by_projection_ff(has_mp, Xw, d0, k0["octave"], k0["angle"], Tcw, Tlw, Trl, cam, params, th, mono=False,
+                                           check_ori=True, mb=0.11, qobs=obs)
+        assert n_gpu == n_ref
+        assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+        total += n_ref
+    assert total > (100 if cam == 0 else 0)
