@@ -5,7 +5,8 @@
 // four #ifndef guards).  Needs the reference's Frame.h / MapPoint.h (OpenCV, Eigen, boost, DBoW2, g2o), so it cannot
 // be built in this repository's image.
 //
-// Replaced members (mono / rectified-stereo / RGB-D frames, Frame::Nleft == -1):
+// Replaced members (the two Frame overloads of SearchByProjection for every frame type, fisheye-stereo included; the
+// KeyFrame overload for Frame::Nleft == -1):
 //   int  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float th, bool bFarPoints, float thFarPoints)  :44-214
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, const Frame &Last, float th, bool bMono)                             :2027-2289
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, KeyFrame *pKF, const set<MapPoint*>&, float th, int ORBdist)       :2291-2413
@@ -13,8 +14,8 @@
 //   int  ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)                                                  :2463-2483
 //   void ORBmatcher::ComputeThreeMaxima(vector<int>*, int, int&, int&, int&)                                             :2416-2458
 //   float ORBmatcher::RadiusByViewingCos(const float&)                                                                   :216-222
-// Fisheye-stereo frames (Nleft != -1) are forwarded to the reference implementation, which INTEGRATION.md keeps
-// available under the name SearchByProjection_ref.
+// The KeyFrame overload forwards fisheye-stereo frames (Nleft != -1) to the reference implementation, which
+// INTEGRATION.md keeps available under the name SearchByProjection_ref.
 #include "ORBmatcher.h"  // the reference's header
 
 #include <stdexcept>
@@ -49,6 +50,21 @@ orbm_frame_t view_of(const Frame &F) {
   return f;
 }
 
+// Fisheye-stereo frame (Nleft != -1): GetFeaturesInArea reads mvKeys / mvKeysRight (Frame.cc:791-793) and mDescriptors
+// already holds both images (Frame.cc:1201); the keypoints are concatenated here.
+orbm_frame_t view_of_fisheye(const Frame &F, std::vector<orbx_keypoint_t> &keys) {
+  keys.resize(F.N);
+  if (F.Nleft > 0) std::memcpy(keys.data(), F.mvKeys.data(), sizeof(orbx_keypoint_t) * (size_t)F.Nleft);
+  if (F.Nright > 0) std::memcpy(keys.data() + F.Nleft, F.mvKeysRight.data(), sizeof(orbx_keypoint_t) * (size_t)F.Nright);
+  orbm_frame_t f;
+  f.n = F.N;
+  f.keys_un = keys.data();
+  f.descriptors = F.mDescriptors.data;
+  f.u_right = nullptr;  // not tested when Nleft != -1 (ORBmatcher.cc:93, :2139)
+  f.min_x = Frame::mnMinX; f.max_x = Frame::mnMaxX; f.min_y = Frame::mnMinY; f.max_y = Frame::mnMaxY;
+  return f;
+}
+
 // F.mvpMapPoints <-> (slot, slot_obs).  Pre-existing occupants get id 2^30 so they are never confused with a query index.
 void slots_of(const Frame &F, std::vector<int32_t> &slot, std::vector<uint8_t> &obs) {
   slot.assign(F.N, -1);
@@ -70,7 +86,53 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int> *histo, const int L, int &i
 
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, const bool bFarPoints,
                                    const float thFarPoints) {
-  if (F.Nleft != -1) return SearchByProjection_ref(F, vpMapPoints, th, bFarPoints, thFarPoints);
+  if (F.Nleft != -1) {
+    // two queries per map point: 2j = left image, 2j+1 = right image (ORBmatcher.cc:145-211)
+    const int nmp = (int)vpMapPoints.size(), nq = 2 * nmp;
+    std::vector<uint8_t> qdesc((size_t)nq * 32), flags(nq, 0);
+    std::vector<float> u(nq, 0.f), v(nq, 0.f), rad(nq, 0.f);
+    std::vector<int32_t> minl(nq, -1), maxl(nq, -1);
+    const bool bFactor = th != 1.0;
+    for (int j = 0; j < nmp; j++) {
+      MapPoint *pMP = vpMapPoints[j];
+      if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;  // :52
+      if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue; // :55
+      if (pMP->isBad()) continue;                                 // :58
+      const uint8_t ob = (uint8_t)((pMP->Observations() > 0 ? 1u : 0u) << 1);
+      const cv::Mat d = pMP->GetDescriptor();
+      std::memcpy(&qdesc[(size_t)(2 * j) * 32], d.ptr<uint8_t>(), 32);
+      std::memcpy(&qdesc[(size_t)(2 * j + 1) * 32], d.ptr<uint8_t>(), 32);
+      if (pMP->mbTrackInView) {
+        const int lvl = pMP->mnTrackScaleLevel;
+        float r = RadiusByViewingCos(pMP->mTrackViewCos);
+        if (bFactor) r *= th;
+        rad[2 * j] = r * F.mvScaleFactors[lvl];
+        u[2 * j] = pMP->mTrackProjX; v[2 * j] = pMP->mTrackProjY;
+        minl[2 * j] = lvl - 1; maxl[2 * j] = lvl;
+        flags[2 * j] = (uint8_t)(1u | ob);
+      }
+      if (pMP->mbTrackInViewR && pMP->mnTrackScaleLevelR != -1) { // :145-147
+        const int lvl = pMP->mnTrackScaleLevelR;
+        const float r = RadiusByViewingCos(pMP->mTrackViewCosR);  // :148, no th factor
+        rad[2 * j + 1] = r * F.mvScaleFactors[lvl];
+        u[2 * j + 1] = pMP->mTrackProjXR; v[2 * j + 1] = pMP->mTrackProjYR;
+        minl[2 * j + 1] = lvl - 1; maxl[2 * j + 1] = lvl;
+        flags[2 * j + 1] = (uint8_t)(1u | ob);
+      }
+    }
+    std::vector<int32_t> slot, moq(nq);
+    std::vector<uint8_t> sobs;
+    slots_of(F, slot, sobs);
+    std::vector<orbx_keypoint_t> keys;
+    const orbm_frame_t f = view_of_fisheye(F, keys);
+    orbm_queries_t qs{nq, qdesc.data(), u.data(), v.data(), rad.data(), minl.data(), maxl.data(), nullptr, flags.data()};
+    const int n = orbm_search_by_projection_fisheye(matcher(), &f, F.Nleft, F.mvLeftToRightMatch.data(), F.mvRightToLeftMatch.data(), &qs,
+                                                    mfNNratio, TH_HIGH, slot.data(), sobs.data(), moq.data(), nullptr);
+    if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
+    for (int i = 0; i < F.N; i++)  // slots written by this call hold a query id: map point = id / 2 (own and partner writes alike)
+      if (slot[i] >= 0 && slot[i] < nq) F.mvpMapPoints[i] = vpMapPoints[slot[i] >> 1];
+    return n;
+  }
   const int nq = (int)vpMapPoints.size();
   std::vector<uint8_t> qdesc((size_t)nq * 32), flags(nq, 0);
   std::vector<float> u(nq, 0.f), v(nq, 0.f), rad(nq, 0.f), ur(nq, 0.f);
@@ -104,14 +166,17 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
 }
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) {
-  if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1) return SearchByProjection_ref(CurrentFrame, LastFrame, th, bMono);
+  const bool fisheye = CurrentFrame.Nleft != -1;
   const int nLast = LastFrame.N;
   std::vector<uint8_t> has(nLast, 0), obs(nLast, 0), desc((size_t)nLast * 32);
   std::vector<float> Xw((size_t)nLast * 3, 0.f);
   std::vector<orbx_keypoint_t> lk(nLast);
   for (int i = 0; i < nLast; i++) {
-    std::memcpy(&lk[i], &LastFrame.mvKeysUn[i], sizeof(orbx_keypoint_t));
-    lk[i].octave = LastFrame.mvKeys[i].octave;
+    // angle: :2168-2170 / octave: :2100 - mvKeysUn / mvKeys, or mvKeys / mvKeysRight for a fisheye-stereo last frame
+    const cv::KeyPoint &kpA = LastFrame.Nleft == -1 ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft]);
+    const cv::KeyPoint &kpO = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+    std::memcpy(&lk[i], &kpA, sizeof(orbx_keypoint_t));
+    lk[i].octave = kpO.octave;
     MapPoint *pMP = LastFrame.mvpMapPoints[i];
     if (!pMP || LastFrame.mvbOutlier[i]) continue;              // :2058-2061
     has[i] = 1;
@@ -130,11 +195,23 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
   std::vector<int32_t> slot;
   std::vector<uint8_t> sobs;
   slots_of(CurrentFrame, slot, sobs);
-  const orbm_frame_t f = view_of(CurrentFrame);
-  const int n = orbm_search_by_projection_last_frame(matcher(), &f, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
-                                                     nLast, has.data(), Xw.data(), desc.data(), lk.data(), obs.data(), Tcw, Tlw, camType,
-                                                     params.data(), CurrentFrame.mb, CurrentFrame.mbf, th, bMono ? 1 : 0,
-                                                     mbCheckOrientation ? 1 : 0, slot.data(), sobs.data());
+  std::vector<orbx_keypoint_t> keys;
+  const orbm_frame_t f = fisheye ? view_of_fisheye(CurrentFrame, keys) : view_of(CurrentFrame);
+  int n;
+  if (fisheye) {
+    float Trl[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) Trl[r * 4 + c] = CurrentFrame.mTrl.at<float>(r, c);  // :2190
+    n = orbm_search_by_projection_last_frame_fisheye(matcher(), &f, CurrentFrame.Nleft, CurrentFrame.mvScaleFactors.data(),
+                                                     (int)CurrentFrame.mvScaleFactors.size(), nLast, has.data(), Xw.data(), desc.data(),
+                                                     lk.data(), obs.data(), Tcw, Tlw, Trl, camType, params.data(), CurrentFrame.mb, th,
+                                                     bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, slot.data(), sobs.data());
+  } else {
+    n = orbm_search_by_projection_last_frame(matcher(), &f, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
+                                             nLast, has.data(), Xw.data(), desc.data(), lk.data(), obs.data(), Tcw, Tlw, camType,
+                                             params.data(), CurrentFrame.mb, CurrentFrame.mbf, th, bMono ? 1 : 0,
+                                             mbCheckOrientation ? 1 : 0, slot.data(), sobs.data());
+  }
   if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
   for (int i = 0; i < CurrentFrame.N; i++) {
     if (slot[i] >= 0 && slot[i] < nLast) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[slot[i]];      // :2162
