@@ -286,7 +286,17 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
 #ifndef FAST_NT
 #define FAST_NT 256
 #endif
+// Diagnostic builds (-DFAST_STAMPS, tools/fast_stamps.py): cycles per section, thread 0 of every workgroup.
+#ifdef FAST_STAMPS
+__device__ unsigned int *g_fast_stamps;  // [workgroup][8] cycle deltas, set by orbx_debug_fast_stamps
+#define FSTAMP(i) do { const long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && g_fast_stamps) g_fast_stamps[(size_t)blockIdx.x * 8 + (i)] = (unsigned int)(t_ - ft0); ft0 = t_; } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
+#ifdef FAST_STAMPS
+  long long ft0 = __builtin_readcyclecounter();
+#endif
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[60 * 60];
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
   if (tid == 0) { sCount = 0; sNList = 0; sNKept = 0; sNOut = 0; }
   __syncthreads();
+  FSTAMP(0);
   const int tmin = min(P.iniTh, P.minTh);
   const uint32_t magicw = 0xffffffffu / (uint32_t)cw + 1u;  // p / cw for p < 2^16 (exact: p*cw < 2^32)
   // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     if (pass) sList[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
   }
   __syncthreads();
+  FSTAMP(1);
   // ---- pass 2: full 16-pixel score for the survivors only
   const int nlist = (int)sNList;
   for (int e = tid; e < nlist; e += FAST_NT) {
@@ -360,6 +372,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
   }
   __syncthreads();
+  FSTAMP(2);
   // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list; vote for
   // the iniThFAST set.  Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
   for (int e = tid; e < nlist; e += FAST_NT) {
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     }
   }
   __syncthreads();
+  FSTAMP(3);
   const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
   uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (4752 B >= 1024 entries): keeps LDS at ~20 KB = 8 workgroups per CU
   const int nkept = (int)sNKept;
@@ -385,6 +399,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     if ((int)(v >> 16) > thr) sOut[atomicAdd(&sNOut, 1u)] = v;
   }
   __syncthreads();
+  FSTAMP(4);
   // ---- pass 4: cv::FAST emits rows ascending, x ascending = ascending p: rank by counting (lists are short)
   const int nout = (int)sNOut;
   uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     if (rank < cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
   }
   if (tid == 0) *cellCnt = min((uint32_t)nout, cellCap);
+  FSTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------------------

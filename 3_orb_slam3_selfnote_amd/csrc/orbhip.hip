@@ -211,6 +211,14 @@ int orbx_get_features_per_level(const orbx_t *h, int *n) {
 // floor(2^32 / n) for xcd_map's division by multiplication (n == 1: the estimate q-1 is corrected on the device)
 static uint32_t magic_div(uint32_t n) { return n <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / n); }
 
+#ifdef FAST_STAMPS
+// diagnostic builds only (tools/fast_stamps.py): device buffer [workgroups][8] of u32 cycle deltas per k_fast section
+int orbx_debug_fast_stamps(void *d_buf) {
+  unsigned int *p = (unsigned int *)d_buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int orbx_max_keypoints(const orbx_t *h) { return h ? h->maxKeypoints : ORBX_E_ARG; }
 
 int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
