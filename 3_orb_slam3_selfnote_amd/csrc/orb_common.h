@@ -67,6 +67,7 @@ struct FrameParams {
   const int2 *xtab, *ytab;          // resize tables {src index, a0 | a1<<16}
   const int8_t *disc;               // ORB_DISC_PIXELS x (u, v)
   const uint32_t *cells;            // FAST cell records, 8 words each (orbx_configure), same for every frame
+  const uint32_t *tiles;            // blur tile records, 8 words each: x0|y0<<16, level, w|h<<16, pitch|bpitch<<16, off, boff
   uint32_t magicCells, magicTiles, magicKpBlk;  // floor(2^32 / items per frame) of k_fast, k_blur, k_describe (xcd_map)
   int totalTiles;                   // blur tiles per frame
   int totalCells;                   // FAST cells per frame

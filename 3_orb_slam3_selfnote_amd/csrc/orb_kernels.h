@@ -278,8 +278,9 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
   const int lo = v - t, hi = v + t;
   const int d0 = p0 - lo, d4 = p4 - lo, d8 = p8 - lo, d12 = p12 - lo;   // negative <=> darker than v - t
   const int b0 = hi - p0, b4 = hi - p4, b8 = hi - p8, b12 = hi - p12;   // negative <=> brighter than v + t
-  const int dd = (d0 & d4) | (d4 & d8) | (d8 & d12) | (d12 & d0);
-  const int bb = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+  // two ADJACENT compass pixels both dark: (d0&d4)|(d4&d8)|(d8&d12)|(d12&d0) = (d0|d8) & (d4|d12) on the sign bits
+  const int dd = (d0 | d8) & (d4 | d12);
+  const int bb = (b0 | b8) & (b4 | b12);
   return (dd | bb) < 0;
 }
 
@@ -741,20 +742,20 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
 __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   // input tile: rows y0-3 .. y0+34 (38), columns x0-4 .. x0+131 (136 B = 34 dwords); row sums: 38 x 128 u16
   __shared__ uint32_t sIn[38 * 34];
-  __shared__ uint32_t sRow[38 * 64];
+  __shared__ __align__(16) uint32_t sRow[19 * 128];  // vertical pairs of row sums: [row pair][column]
   const int tid = threadIdx.x;
   int tile, frame;
   xcd_map(P.totalTiles, P.magicTiles, P.nframes, frame, tile);
-  int level = 0;
-#pragma unroll
-  for (int l = 1; l < ORB_MAXL; l++)  // constant trip count: the scalar loads are independent and issue together
-    if (l < P.nlevels && tile >= P.geom[l].tileBase) level = l;
-  const LevelGeom G = P.geom[level];
-  const int t = tile - G.tileBase;
-  const int ty = t / G.tilesX, tx = t - ty * G.tilesX;
-  const int x0 = tx * BLUR_TX, y0 = ty * BLUR_TY;
+  // tile record (orbx_configure): origin, level size and plane offsets in one 32-byte scalar load
+  const uint4 t0 = reinterpret_cast<const uint4 *>(P.tiles)[2 * tile], t1 = reinterpret_cast<const uint4 *>(P.tiles)[2 * tile + 1];
+  const int x0 = (int)(t0.x & 0xffffu), y0 = (int)(t0.x >> 16), level = (int)t0.y;
+  struct { int w, h, bpitch; size_t boff; } G;
+  G.w = (int)(t0.z & 0xffffu); G.h = (int)(t0.z >> 16); G.bpitch = (int)(t0.w >> 16);
+  G.boff = ((size_t)t1.w << 32) | t1.z;
   int pitch;
-  const uint8_t *img = level_plane(P, frame, level, pitch);
+  const uint8_t *img;
+  if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
+  else { pitch = (int)(t0.w & 0xffffu); img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)t1.y << 32) | t1.x); }
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
   // interior tiles (the majority): no reflection anywhere, plain coalesced dword rows.  Decided once per workgroup.
   const bool interior = aligned && x0 >= 4 && x0 + BLUR_TX + 4 <= G.w && y0 >= 3 && y0 + BLUR_TY + 3 <= G.h;
@@ -765,63 +766,93 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
       sIn[idx] = *reinterpret_cast<const uint32_t *>(base + (size_t)r * pitch + 4 * c);
     }
   } else {
+    // border tiles: one reflection step is enough whenever the level is larger than the halo (always, except degenerate
+    // configurations, which take the general loop); columns far beyond the right edge only feed outputs nobody stores
+    const bool small = G.w < 16 || G.h < 16;
     for (int idx = tid; idx < 38 * 34; idx += 256) {
       const int r = idx / 34, c = idx - r * 34;
-      const int yy = reflect101(y0 + r - 3, G.h);
+      int yy = y0 + r - 3;
+      if (small) yy = reflect101(yy, G.h);
+      else { yy = yy < 0 ? -yy : yy; yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy; yy = max(yy, 0); }
       const int xb = x0 - 4 + 4 * c;
       const uint8_t *row = img + (size_t)yy * pitch;
       uint32_t v;
       if (aligned && xb >= 0 && xb + 3 < G.w) {
         v = *reinterpret_cast<const uint32_t *>(row + xb);
-      } else {
+      } else if (small) {
         v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
             ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
+      } else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int xx = xb + k;
+          xx = xx < 0 ? -xx : xx;
+          xx = xx >= G.w ? 2 * (G.w - 1) - xx : xx;
+          xx = max(xx, 0);                      // only for columns >= w + w - 1: never part of a stored output
+          v |= (uint32_t)row[xx] << (8 * k);
+        }
       }
       sIn[idx] = v;
     }
   }
   __syncthreads();
-  // horizontal pass: thread = 4 consecutive outputs of one row; taps as two byte-quads for v_dot4_u32_u8
+  // horizontal pass: task = 4 consecutive outputs of TWO vertically adjacent rows; taps as two byte-quads for
+  // v_dot4_u32_u8.  The row sums (<= 257*255 = 65535: exact in 16 bits) are stored as vertical pairs
+  // (row 2k | row 2k+1 << 16) per column, which is what the vertical pass's v_dot2_u32_u16 consumes.
   const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
-  for (int idx = tid; idx < 38 * 32; idx += 256) {
-    const int r = idx >> 5, q = idx & 31;
-    const uint32_t d0 = sIn[r * 34 + q], d1 = sIn[r * 34 + q + 1], d2 = sIn[r * 34 + q + 2];
+  auto hsum4 = [&](const uint32_t *row, uint32_t (&o)[4]) {
+    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
     // output k (x = x0+4q+k) uses bytes [1+k, 7+k] of the 12-byte window d0|d1|d2
-    uint32_t s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false);
-    s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, s0, false);
-    uint32_t s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false);
-    s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, s1, false);
-    uint32_t s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false);
-    s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, s2, false);
-    uint32_t s3 = __builtin_amdgcn_udot4(d1, K0, 0u, false);
-    s3 = __builtin_amdgcn_udot4(d2, K1, s3, false);
-    sRow[r * 64 + 2 * q] = s0 | (s1 << 16);        // row sums <= 257*255 = 65535: exact in 16 bits
-    sRow[r * 64 + 2 * q + 1] = s2 | (s3 << 16);
+    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+    o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+  };
+  for (int idx = tid; idx < 19 * 32; idx += 256) {
+    const int rp = idx >> 5, q = idx & 31;
+    uint32_t sa[4], sb[4];
+    hsum4(&sIn[(2 * rp) * 34 + q], sa);
+    hsum4(&sIn[(2 * rp + 1) * 34 + q], sb);
+    *reinterpret_cast<uint4 *>(&sRow[rp * 128 + 4 * q]) = make_uint4(sa[0] | (sb[0] << 16), sa[1] | (sb[1] << 16), sa[2] | (sb[2] << 16), sa[3] | (sb[3] << 16));
   }
   __syncthreads();
-  // vertical pass: thread = 4 columns x 4 rows, 10-row window read once
+  // vertical pass: thread = 4 columns x 4 rows; the 10-row window = 5 row pairs per column, read once (5 x b128).
+  // Output row y0+4rg+rr uses tile rows 4rg+rr .. +6: even rr take the stored pairs, odd rr the pairs shifted by one row
+  // (v_alignbit); 4 x v_dot2_u32_u16 per output, the rounding constant rides in the accumulator.
   {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const int q = tid & 31, rg = tid >> 5;  // column quad 0..31, row group 0..7
-    uint32_t a[10], b[10];
+    uint4 RP[5];
 #pragma unroll
-    for (int j = 0; j < 10; j++) { a[j] = sRow[(rg * 4 + j) * 64 + 2 * q]; b[j] = sRow[(rg * 4 + j) * 64 + 2 * q + 1]; }
+    for (int j = 0; j < 5; j++) RP[j] = *reinterpret_cast<const uint4 *>(&sRow[(rg * 2 + j) * 128 + 4 * q]);
+    const us2 K01 = {18, 34}, K23 = {49, 55}, K45 = {49, 34}, K6 = {18, 0};
+    auto d2 = [](uint32_t a, us2 k, uint32_t acc) { return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), k, acc, false); };
+    uint32_t px[4][4];  // [row][column]
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+      uint32_t p[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) p[j] = cc == 0 ? RP[j].x : cc == 1 ? RP[j].y : cc == 2 ? RP[j].z : RP[j].w;
+      uint32_t qv[5];
+#pragma unroll
+      for (int j = 0; j < 4; j++) qv[j] = __builtin_amdgcn_alignbit(p[j + 1], p[j], 16);  // (row 2j+1, row 2j+2)
+      qv[4] = p[4] >> 16;
+      const uint32_t v0 = d2(p[3], K6, d2(p[2], K45, d2(p[1], K23, d2(p[0], K01, 32768u))));
+      const uint32_t v1 = d2(qv[3], K6, d2(qv[2], K45, d2(qv[1], K23, d2(qv[0], K01, 32768u))));
+      const uint32_t v2 = d2(p[4], K6, d2(p[3], K45, d2(p[2], K23, d2(p[1], K01, 32768u))));
+      const uint32_t v3 = d2(qv[4], K6, d2(qv[3], K45, d2(qv[2], K23, d2(qv[1], K01, 32768u))));
+      px[0][cc] = min(v0 >> 16, 255u); px[1][cc] = min(v1 >> 16, 255u);
+      px[2][cc] = min(v2 >> 16, 255u); px[3][cc] = min(v3 >> 16, 255u);
+    }
     uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      uint32_t px[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++) {
-#define RS(j) ((cc < 2 ? a[rr + (j)] : b[rr + (j)]) >> ((cc & 1) * 16) & 0xffffu)
-        uint32_t v = 18u * (RS(0) + RS(6)) + 34u * (RS(1) + RS(5)) + 49u * (RS(2) + RS(4)) + 55u * RS(3);
-#undef RS
-        v = (v + 32768u) >> 16;
-        px[cc] = v > 255u ? 255u : v;
-      }
       const int y = y0 + rg * 4 + rr, x = x0 + 4 * q;
       if (y < G.h) {
         uint8_t *o = out + (size_t)y * G.bpitch + x;
-        if (x + 3 < G.w) *reinterpret_cast<uint32_t *>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-        else for (int cc = 0; cc < 4 && x + cc < G.w; cc++) o[cc] = (uint8_t)px[cc];
+        if (x + 3 < G.w) *reinterpret_cast<uint32_t *>(o) = px[rr][0] | (px[rr][1] << 8) | (px[rr][2] << 16) | (px[rr][3] << 24);
+        else for (int cc = 0; cc < 4 && x + cc < G.w; cc++) o[cc] = (uint8_t)px[rr][cc];
       }
     }
   }

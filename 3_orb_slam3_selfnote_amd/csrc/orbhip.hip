@@ -68,7 +68,7 @@ struct orbx_handle {
   int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
-  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_xtab,
+  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_tiles, d_xtab,
       d_ytab, d_disc;
   DevBuf d_img, d_okps, d_odesc, d_ocounts;  // staging for the host entry point
   hipStream_t stream = nullptr;
@@ -179,7 +179,7 @@ void orbx_destroy(orbx_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
-                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
   if (h->ev_ok)
     for (auto &e : h->ev) (void)hipEventDestroy(e);
@@ -341,6 +341,22 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         R[7] = (uint32_t)((uint64_t)G.off >> 32);
       }
   }
+  // blur tile records (k_blur)
+  std::vector<uint32_t> tilerec((size_t)std::max(tiles, 1) * 8, 0u);
+  for (int l = 0; l < nl; l++) {
+    const LevelGeom &G = g[l];
+    if (G.pitch > 65535 || G.bpitch > 65535) { h->err = "level pitch above 65535"; return ORBX_E_ARG; }
+    for (int ty = 0; ty < G.tilesY; ty++)
+      for (int tx = 0; tx < G.tilesX; tx++) {
+        uint32_t *R = &tilerec[(size_t)(G.tileBase + ty * G.tilesX + tx) * 8];
+        R[0] = (uint32_t)(tx * BLUR_TX) | ((uint32_t)(ty * BLUR_TY) << 16);
+        R[1] = (uint32_t)l;
+        R[2] = (uint32_t)G.w | ((uint32_t)G.h << 16);
+        R[3] = (uint32_t)G.pitch | ((uint32_t)G.bpitch << 16);
+        R[4] = (uint32_t)(G.off & 0xffffffffu); R[5] = (uint32_t)((uint64_t)G.off >> 32);
+        R[6] = (uint32_t)(G.boff & 0xffffffffu); R[7] = (uint32_t)((uint64_t)G.boff >> 32);
+      }
+  }
   h->geom = g;
   h->pyr_fs = std::max<size_t>(pyr, 256);
   h->blur_fs = blur;
@@ -367,6 +383,8 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_candCnt.reserve(sizeof(int32_t) * nl * B));
   XCHECK(h, h->d_cells.reserve(sizeof(uint32_t) * cellrec.size()));
   XCHECK(h, hipMemcpy(h->d_cells.p, cellrec.data(), sizeof(uint32_t) * cellrec.size(), hipMemcpyHostToDevice));
+  XCHECK(h, h->d_tiles.reserve(sizeof(uint32_t) * tilerec.size()));
+  XCHECK(h, hipMemcpy(h->d_tiles.p, tilerec.data(), sizeof(uint32_t) * tilerec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_xtab.reserve(sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
   XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
   if (!xtab.empty()) XCHECK(h, hipMemcpy(h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
@@ -451,6 +469,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   P.totalTiles = h->totalTiles;
   P.totalCells = h->totalCells;
   P.cells = (const uint32_t *)h->d_cells.p;
+  P.tiles = (const uint32_t *)h->d_tiles.p;
   P.magicCells = magic_div((uint32_t)std::max(h->totalCells, 1));
   P.magicTiles = magic_div((uint32_t)std::max(h->totalTiles, 1));
   P.magicKpBlk = magic_div((uint32_t)std::max((h->totalKp + 3) / 4, 1));
