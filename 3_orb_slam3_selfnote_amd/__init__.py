@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -115,6 +115,7 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection_fisheye.argtypes = [vp, vp, i32, vp, vp, vp, f32, i32, vp, vp, vp, vp]
     L.orbm_search_by_projection_last_frame_fisheye.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32,
                                                                i32, i32, vp, vp]
+    L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
@@ -501,6 +502,19 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_search_by_projection_last_frame_fisheye rc=%d" % rc)
         return rc
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """SearchForInitialization(Frame &F1, Frame &F2, vbPrevMatched, vnMatches12, windowSize) -- ORBmatcher.cc:722-837.
+        F1, F2: FrameView; vbPrevMatched: (N1, 2) float32, updated in place.  Returns (nmatches, vnMatches12)."""
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags["C_CONTIGUOUS"] and vbPrevMatched.shape == (F1.N, 2)
+        m12 = np.full(F1.N, -1, dtype=np.int32)
+        f1, f2 = F1.struct(), F2.struct()
+        rc = self.L.orbm_search_for_initialization(self.m, C.byref(f1), C.byref(f2), _p(vbPrevMatched), int(windowSize),
+                                                   C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m12))
+        self._check(rc, "orbm_search_for_initialization")
+        if rc < 0:
+            raise OrbError("orbm_search_for_initialization rc=%d" % rc)
+        return rc, m12
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

@@ -11,6 +11,7 @@
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, const Frame &Last, float th, bool bMono)                             :2027-2289
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, KeyFrame *pKF, const set<MapPoint*>&, float th, int ORBdist)       :2291-2413
 //   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool, bool) :981-1222
+//   int  ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f>&, vector<int>&, int windowSize)  :722-837
 //   int  ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)                                                  :2463-2483
 //   void ORBmatcher::ComputeThreeMaxima(vector<int>*, int, int&, int&, int&)                                             :2416-2458
 //   float ORBmatcher::RadiusByViewingCos(const float&)                                                                   :216-222
@@ -217,6 +218,18 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     if (slot[i] >= 0 && slot[i] < nLast) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[slot[i]];      // :2162
     else if (slot[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);                     // :2279 (pruned)
   }
+  return n;
+}
+
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,
+                                        int windowSize) {
+  vnMatches12.assign(F1.mvKeysUn.size(), -1);                    // :725
+  orbm_frame_t f1 = view_of(F1), f2 = view_of(F2);
+  f1.n = (int)F1.mvKeysUn.size(); f2.n = (int)F2.mvKeysUn.size();
+  static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "cv::Point2f is two floats");
+  const int n = orbm_search_for_initialization(matcher(), &f1, &f2, reinterpret_cast<float *>(vbPrevMatched.data()), windowSize, mfNNratio,
+                                               mbCheckOrientation ? 1 : 0, vnMatches12.data());
+  if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
   return n;
 }
 

@@ -687,6 +687,102 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   }
 }
 
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:722-837): the sequential state is vMatchedDistance[i2], the
+// distance at which keypoint i2 of F2 is currently matched; a later query sees i2 only while its own distance is
+// SMALLER (:762), so visibility shrinks monotonically and k_match_scan's sorted top-8 list of a query stays the head of
+// its visible candidates.  One wavefront walks the queries in order: lanes 0..7 test the visibility of the 8 entries
+// (one ballot), the first two visible ones are best / second (:765-774); the accept rule is :777-779.  If fewer than two
+// are visible and an unlisted candidate could still change the decision, the wave rescans all keypoints of F2 exactly.
+// Runs once per monocular initialisation attempt (Tracking.cc:2471), so one wavefront per problem is enough.
+// Output: match_of_query[q] = keypoint accepted AT q's turn (or -1), best_dist[q] = its distance; the caller replays the
+// steals (:781-785) and the rotation histogram, which need the accept-time pairs.
+template <typename KT>
+__global__ __launch_bounds__(64) void k_init_resolve(MatchProblemSet M, const typename KT::T *topk, int th_low) {
+  typedef typename KT::T K;
+  extern __shared__ __align__(16) uint32_t smem_init[];
+  __shared__ K sTk[MATCH_TOPK * 64];
+  const int lane = threadIdx.x;
+  const int p = blockIdx.x;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
+  const float *kp = M.kp + fo * 7;
+  const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
+  uint16_t *sVMD = reinterpret_cast<uint16_t *>(smem_init);  // vMatchedDistance, 0xffff = INT_MAX (:733)
+  for (int i = lane; i < n; i += 64) sVMD[i] = 0xffff;
+  __builtin_amdgcn_s_barrier();
+  int nacc = 0;
+  for (int base = 0; base < nq; base += 64) {
+    const int q = base + lane, cnt = min(64, nq - base);
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + lane] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+    int res_idx = -1, res_bd = 256;
+    for (int i = 0; i < cnt; i++) {
+      // lanes 0..7: entry `lane` of query base+i
+      const K k = lane < MATCH_TOPK ? sTk[64 * lane + i] : KT::NONE;
+      const bool valid = k != KT::NONE;
+      const int c = valid ? KT::idx(k) : 0, d = KT::dist(k);
+      const bool vis = valid && (int)sVMD[c] > d;                                   // :762
+      const uint32_t b = (uint32_t)__ballot(vis) & ((1u << MATCH_TOPK) - 1u);
+      const int found = __popc(b);
+      const int j1 = b ? __builtin_ctz(b) : 0, j2 = (b & (b - 1u)) ? __builtin_ctz(b & (b - 1u)) : 0;
+      int bd = found > 0 ? __builtin_amdgcn_readlane(d, j1) : 0x7fffffff;
+      int bd2 = found > 1 ? __builtin_amdgcn_readlane(d, j2) : 0x7fffffff;
+      int best = found > 0 ? __builtin_amdgcn_readlane(c, j1) : -1;
+      const K last = KT::readlane(k, MATCH_TOPK - 1);
+      const bool truncated = last != KT::NONE;
+      const int lbDist = KT::dist(last);
+      bool rescan = false;
+      if (truncated) {
+        if (found == 0) rescan = lbDist <= th_low;
+        else if (found == 1) rescan = bd <= th_low && !((float)bd < (float)lbDist * M.nnratio);
+      }
+      if (rescan) {  // exact best / second among the visible keypoints of the window, whole wavefront
+        const QueryWin w = load_query(M, qo, base + i);
+        const uint32_t *qd = reinterpret_cast<const uint32_t *>(M.qdesc + (qo + base + i) * 32);
+        uint32_t q8[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) q8[t] = qd[t];
+        K b1 = KT::NONE, b2 = KT::NONE;
+        if (w.live) {
+          for (int cc = lane; cc < n; cc += 64) {
+            const float x = kp[(size_t)cc * 7], y = kp[(size_t)cc * 7 + 1];
+            const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)cc * 7 + 5]), false, M);
+            if (cand_passes(w, x, y, bits, -1.f)) {
+              int dist = 0;
+#pragma unroll
+              for (int t = 0; t < 8; t++) dist += __popc(desc[(size_t)cc * 8 + t] ^ q8[t]);
+              if ((int)sVMD[cc] > dist) {
+                const K key = KT::make(dist, cell_of(bits), cc);
+                if (key < b1) { b2 = b1; b1 = key; }
+                else if (key < b2) b2 = key;
+              }
+            }
+          }
+        }
+        const K g1 = wave_min_key(b1);
+        const K g2 = wave_min_key((b1 == g1) ? b2 : b1);
+        bd = g1 != KT::NONE ? KT::dist(g1) : 0x7fffffff;
+        bd2 = g2 != KT::NONE ? KT::dist(g2) : 0x7fffffff;
+        best = g1 != KT::NONE ? KT::idx(g1) : -1;
+      }
+      // :777-779  bestDist<=TH_LOW && bestDist<(float)bestDist2*mfNNratio   (bestDist2 == INT_MAX when there is no second)
+      const bool accept = best >= 0 && bd <= th_low && (float)bd < (float)bd2 * M.nnratio;
+      if (accept) {
+        if (lane == 0) sVMD[best] = (uint16_t)bd;                                   // :788
+        nacc++;
+      }
+      if (lane == i) { res_idx = accept ? best : -1; res_bd = accept ? bd : 256; }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (q < nq) {
+      if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
+      if (M.best_dist) M.best_dist[qo + q] = res_bd;
+    }
+  }
+  if (lane == 0 && M.nmatches) M.nmatches[p] = nacc;
+}
+
 // SearchForTriangulation inner loops (ORBmatcher.cc:1080-1153): one wavefront per unmatched keypoint of KF1, lanes over
 // the keypoints of KF2 in the same vocabulary node.  The reference keeps a running best with `dist>bestDist -> skip`
 // and updates it only when the geometric gates pass, i.e. the result is the LAST minimum among the gated candidates

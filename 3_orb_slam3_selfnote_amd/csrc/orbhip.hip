@@ -634,7 +634,7 @@ struct orbm_handle {
   DevBuf d_partner, d_qside, d_qany;
   // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
   // orbm_search_by_projection_batch_device): device pointers
-  struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; } ext;
+  struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; int init_th_low = -1; } ext;
   bool profiling = false;
   hipEvent_t ev[3] = {};
   bool ev_ok = false, ms_valid = false;
@@ -819,6 +819,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
 #endif
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
   M.serial = m->ext.serial; M.qany = m->ext.qany;
+  const int init_th_low = m->ext.init_th_low;  // >= 0: SearchForInitialization's resolve instead of the claim loop
   m->ext = {};
   const int maxn = d_frame_n ? frame_stride : f->n;
   const int maxq = d_query_n ? query_stride : q->nq;
@@ -849,7 +850,10 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, true>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);       \
     else hipLaunchKernelGGL((k_match_scan<KT, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
     if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
-    hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);     \
+    if (init_th_low >= 0)                                                                                                 \
+      hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);   \
   } while (0)
   if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
   else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
@@ -860,7 +864,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
 }
 
 // host-pointer fisheye-stereo options of one search (see MatchProblemSet)
-struct StereoExt { int nleft; const int32_t *partner; const uint8_t *qside; int couple; int serial; };
+struct StereoExt { int nleft; const int32_t *partner; const uint8_t *qside; int couple; int serial; int init_th_low = -1; };
 
 static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist, int use_second,
                        int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist, const StereoExt *ext);
@@ -910,6 +914,7 @@ static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q
     m->ext.couple = ext->couple;
     m->ext.serial = ext->serial;
     m->ext.qany = ext->couple == 2 ? (uint8_t *)m->d_qany.p : nullptr;
+    m->ext.init_th_low = ext->init_th_low;
   }
 #undef UP
   MCHECK(m, m->d_moq.reserve(sizeof(int32_t) * (size_t)nq));
@@ -1379,6 +1384,71 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *k1, const or
       for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
     }
   }
+  return nmatches;
+}
+
+int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm_frame_t *f2, float *prev_matched, int window_size,
+                                   float nnratio, int checkOri, int32_t *matches12) {
+  if (!m || !f1 || !f2 || !matches12 || f1->n < 0 || f2->n < 0) return ORBX_E_ARG;
+  if (f1->n > 0 && (!f1->keys_un || !f1->descriptors || !prev_matched)) return ORBX_E_ARG;
+  const int n1 = f1->n;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;                 // :725
+  // queries: the level-0 keypoints of F1 in index order (:737-739), window centre = vbPrevMatched (:741)
+  std::vector<int32_t> qi;
+  for (int i = 0; i < n1; i++)
+    if (f1->keys_un[i].octave <= 0) qi.push_back(i);
+  const int nq = (int)qi.size();
+  if (nq == 0 || f2->n == 0) return 0;
+  std::vector<float> u(nq), v(nq), rad(nq, (float)window_size);
+  std::vector<int32_t> lvl(nq, 0), acc(nq, -1);
+  std::vector<uint8_t> qd((size_t)nq * 32);
+  for (int k = 0; k < nq; k++) {
+    u[k] = prev_matched[2 * qi[k]]; v[k] = prev_matched[2 * qi[k] + 1];
+    memcpy(&qd[(size_t)k * 32], f1->descriptors + (size_t)qi[k] * 32, 32);
+  }
+  orbm_queries_t q;
+  q.nq = nq; q.descriptors = qd.data(); q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = lvl.data(); q.max_level = lvl.data();             // GetFeaturesInArea(..., level1, level1), level1 == 0
+  q.u_r = nullptr; q.flags = nullptr;
+  orbm_frame_t f = *f2;
+  f.u_right = nullptr;
+  std::vector<int32_t> slot((size_t)f2->n, -1);
+  std::vector<uint8_t> sobs((size_t)f2->n, 0);
+  StereoExt ext{};
+  ext.nleft = f2->n; ext.init_th_low = ORBM_TH_LOW;
+  const int rc = search_host(m, &f, &q, nnratio, ORBM_TH_LOW, 1, slot.data(), sobs.data(), acc.data(), nullptr, &ext);
+  if (rc < 0) return rc;
+  // replay of the bookkeeping the device leaves to the host: steals (:781-785) and the rotation histogram (:791-801)
+  int nmatches = 0;
+  std::vector<int32_t> m21((size_t)f2->n, -1);
+  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+  const float factor = 1.0f / ORBM_HISTO_LENGTH;
+  for (int k = 0; k < nq; k++) {
+    const int i2 = acc[k];
+    if (i2 < 0) continue;
+    const int i1 = qi[k];
+    if (m21[i2] >= 0) { matches12[m21[i2]] = -1; nmatches--; }
+    matches12[i1] = i2; m21[i2] = i1; nmatches++;
+    if (checkOri) {
+      float rot = f1->keys_un[i1].angle - f2->keys_un[i2].angle;
+      if ((double)rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == ORBM_HISTO_LENGTH) bin = 0;
+      if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(i1);
+    }
+  }
+  if (checkOri) {
+    int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+    orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }   // :815-819
+    }
+  }
+  for (int i = 0; i < n1; i++)                                     // :826-828
+    if (matches12[i] >= 0) { prev_matched[2 * i] = f2->keys_un[matches12[i]].x; prev_matched[2 * i + 1] = f2->keys_un[matches12[i]].y; }
   return nmatches;
 }
 

@@ -274,6 +274,17 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *kf1, const o
                                   const float *cam1, const float *cam2, int bOnlyStereo, int bCoarse, int checkOri,
                                   int32_t *matches12);
 
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
+ *                                         vector<int> &vnMatches12, int windowSize)              (ORBmatcher.cc:722-837)
+ * f1 / f2: mvKeysUn + mDescriptors of the two frames (f2 with its image bounds; u_right unused); prev_matched[2*n1]
+ * (in/out) = vbPrevMatched; matches12[n1] (out) = vnMatches12.  nnratio / checkOri = mfNNratio / mbCheckOrientation.
+ * Only level-0 keypoints of F1 take part (:737-739) and, through the level window, only level-0 keypoints of F2.
+ * The per-query window search + Hamming runs in the projection-search scan kernel, the sequential
+ * vMatchedDistance rule (:762, :788) in one wavefront on the device; the steal bookkeeping (:781-785), the rotation
+ * histogram and the vbPrevMatched update are replayed on the host.  Returns nmatches. */
+int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm_frame_t *f2, float *prev_matched,
+                                   int window_size, float nnratio, int checkOri, int32_t *matches12);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

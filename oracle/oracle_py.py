@@ -78,6 +78,7 @@ def lib():
         _lib.orc_search_by_projection_mp_fisheye.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 12 + [C.c_float, C.c_float] + [C.c_void_p] * 4)
         _lib.orc_search_by_projection_ff_fisheye.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p] +
                                                              [C.c_float] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        _lib.orc_search_for_initialization.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         _lib.orc_frame_init.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p, C.c_int]
     return _lib
 
@@ -271,6 +272,17 @@ class OracleFrame:
                                                   _p(last_angle), _p(qobs), _p(Tcw), _p(Tlw), int(cam_type), _p(cam_params),
                                                   C.c_float(mb), C.c_float(mbf), C.c_float(th), int(mono), int(check_ori),
                                                   _p(self.slot), _p(self.slot_obs))
+
+
+def search_for_initialization(keys1, desc1, F2, prev_matched, window_size, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:722-837); F2 = OracleFrame; prev_matched (n1, 2) float32 in/out."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    n1 = len(keys1)
+    octave, angle, desc1 = a(keys1["octave"], np.int32), a(keys1["angle"], np.float32), a(desc1, np.uint8)
+    m12 = np.full(n1, -1, np.int32)
+    n = lib().orc_search_for_initialization(n1, _p(octave), _p(angle), _p(desc1), C.byref(F2.f), _p(prev_matched), int(window_size),
+                                            C.c_float(nnratio), int(check_ori), _p(m12))
+    return n, m12
 
 
 class OracleFisheyeFrame:

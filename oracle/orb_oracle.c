@@ -1292,6 +1292,73 @@ int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* N2: ORBmatcher::SearchForInitialization, ORBmatcher.cc:722-837                                 */
+/* F1 side: octave / angle / descriptors of mvKeysUn; F2 = orc_frame; prevMatched[2*n1] in/out.    */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_for_initialization(int n1, const int32_t *octave1, const float *angle1, const uint8_t *desc1, orc_frame *F2,
+                                  float *prevMatched, int windowSize, float nnratio, int checkOri, int32_t *vnMatches12) {
+  int nmatches = 0;
+  const int HISTO_LENGTH = 30, TH_LOW = 50;
+  const int n2 = F2->N;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)(n2 + 1));
+  int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)(n2 + 1));
+  for (int i = 0; i < n2; i++) { vMatchedDistance[i] = 2147483647; vnMatches21[i] = -1; }
+  int32_t *vIndices2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int level1 = octave1[i1];
+    if (level1 > 0) continue;
+    const int nv = orc_get_features_in_area(F2, prevMatched[2 * i1], prevMatched[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+    if (nv == 0) continue;
+    const uint8_t *d1 = desc1 + 32 * (size_t)i1;
+    int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+    for (int k = 0; k < nv; k++) {
+      const int i2 = vIndices2[k];
+      const int dist = orc_descriptor_distance(d1, F2->desc + 32 * (size_t)i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if ((float)bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (checkOri) {
+          float rot = angle1[i1] - F2->angle[bestIdx2];
+          if ((double)rot < 0.0) rot += 360.0f;
+          int bin = (int)roundf(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin][rotN[bin]++] = i1;
+        }
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < rotN[i]; j++) {
+        const int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (vnMatches12[i1] >= 0) { prevMatched[2 * i1] = F2->kx[vnMatches12[i1]]; prevMatched[2 * i1 + 1] = F2->ky[vnMatches12[i1]]; }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  free(vMatchedDistance); free(vnMatches21); free(vIndices2);
+  return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* M6, ORBmatcher.cc:981-1222 + Pinhole::epipolarConstrain, Pinhole.cpp:143-165                 */
 /* cv::Mat algebra restated per SURVEY.md A.8 [OPENCV-UNVERIFIED]:                              */
 /*  - 3x3 * 3x3 / 3x3 * 3x1 products without flags: float dot products (a0*b0+a1*b1+a2*b2 in    */

@@ -169,6 +169,10 @@ int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast,
                                         int camType, const float *camParams, float mb, float th, int bMono, int checkOri,
                                         int32_t *slot, uint8_t *slot_obs);
 
+/* N2: ORBmatcher::SearchForInitialization, ORBmatcher.cc:722-837. */
+int orc_search_for_initialization(int n1, const int32_t *octave1, const float *angle1, const uint8_t *desc1, orc_frame *F2,
+                                  float *prevMatched, int windowSize, float nnratio, int checkOri, int32_t *vnMatches12);
+
 /* The slice of KeyFrame that SearchForTriangulation reads. */
 typedef struct {
   int N;

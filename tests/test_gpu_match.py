@@ -373,3 +373,32 @@ def test_search_by_projection_last_frame_m3_fisheye(pkg, oracle, synth, matcher,
         assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
         total += n_ref
     assert total > (100 if cam == 0 else 0)
+
+
+@pytest.mark.parametrize("nfeatures,window", [(1000, 100), (5000, 100), (5000, 30)])
+def test_search_for_initialization_n2(pkg, oracle, synth, nfeatures, window):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:722-837): level-0 window search with the vMatchedDistance rule,
+    match stealing, rotation histogram and the vbPrevMatched update.  5000 features = the initialisation extractor
+    (Tracking.cc:838-844), which takes the 64-bit-key path."""
+    frames, offs = synth.make_stream(3700 + nfeatures, 2)
+    cfg = dict(EUROC); cfg["nfeatures"] = nfeatures
+    o = oracle.OracleExtractor(**cfg)
+    (_, k0, d0), (_, k1, d1) = o.extract(frames[0]), o.extract(frames[1])
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    m = pkg.ORBmatcher(0.9, True)                                     # Tracking.cc:2471: ORBmatcher matcher(0.9,true)
+    try:
+        prev_gpu = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32).copy()   # vbPrevMatched starts at F1's keypoints
+        prev_ref = prev_gpu.copy()
+        total = 0
+        for rnd in range(2):                                          # second round starts from the updated vbPrevMatched
+            F1, F2 = pkg.FrameView(k0, d0, bounds), pkg.FrameView(k1, d1, bounds)
+            OF2 = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, o.scale_factors)
+            n_gpu, m_gpu = m.SearchForInitialization(F1, F2, prev_gpu, window)
+            n_ref, m_ref = oracle.search_for_initialization(k0, d0, OF2, prev_ref, window, 0.9, True)
+            assert n_gpu == n_ref
+            assert np.array_equal(m_gpu, m_ref)
+            assert np.array_equal(prev_gpu, prev_ref)
+            total += n_ref
+        assert total > 50
+    finally:
+        m.close()
