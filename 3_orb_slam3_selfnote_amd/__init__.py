@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
-    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy",
+    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
@@ -99,6 +99,7 @@ def load(build_if_needed=True):
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
     L.orbx_calibration_copy.argtypes = [vp, vp, sz, vp]
+    L.orbx_compute_stereo_matches.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp]
     L.orbx_ref_cosf.restype = f32
     L.orbx_ref_cosf.argtypes = [f32]
     L.orbx_ref_sinf.restype = f32
@@ -236,6 +237,19 @@ class ORBextractor:
             raise OrbError("keypoint capacity bound violated: %d > %d" % (n.value, cap))
         self._check(rc, "orbx_extract")
         return rc, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def ComputeStereoMatches(self, right, keysL, descL, keysR, descR, mb, mbf, frame_l=0, frame_r=0):
+        """Frame::ComputeStereoMatches (Frame.cc:901-1079).  self / right = mpORBextractorLeft / Right after extracting the two
+        images (their pyramids are still on the device).  Returns (mvuRight, mvDepth)."""
+        keysL, keysR = np.ascontiguousarray(keysL, dtype=KP_DTYPE), np.ascontiguousarray(keysR, dtype=KP_DTYPE)
+        descL, descR = np.ascontiguousarray(descL, dtype=np.uint8), np.ascontiguousarray(descR, dtype=np.uint8)
+        uR = np.full(len(keysL), -1, dtype=np.float32)
+        depth = np.full(len(keysL), -1, dtype=np.float32)
+        rc = self.L.orbx_compute_stereo_matches(self.h, int(frame_l), right.h, int(frame_r), len(keysL), _p(keysL), _p(descL), len(keysR),
+                                                _p(keysR), _p(descR), C.c_float(mb), C.c_float(mbf), _p(uR), _p(depth))
+        if rc < 0:
+            raise OrbError("orbx_compute_stereo_matches rc=%d: %s" % (rc, self.L.orbx_last_error(self.h).decode()))
+        return uR, depth
 
     def extract_batch_device(self, d_images, rows, cols, stride, frame_stride, nframes, d_kps, d_desc, d_counts, cap,
                              vLappingArea=(0, 1000), stream=None):

@@ -40,6 +40,9 @@ int device_from_env() {
 // optional knob for monocular pipelines that never read mvImagePyramid: skips the 1.1 MB/frame download
 void ORBHIP_SetFillPyramid(bool on) { g_fill_pyramid = on; }
 
+// the liborbhip handle behind an extractor, for Frame::ComputeStereoMatches -> orbx_compute_stereo_matches
+orbx_t *ORBHIP_Handle(const ORBextractor *e) { return handle_of(e); }
+
 static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint_t), "cv::KeyPoint must be the 28-byte POD of OpenCV 2.4/3.x");
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)

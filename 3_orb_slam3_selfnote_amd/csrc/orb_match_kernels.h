@@ -874,3 +874,116 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t *q, int n
     __syncthreads();
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// N1: Frame::ComputeStereoMatches (Frame.cc:901-1079), rectified stereo: one wavefront per LEFT keypoint.
+//   1. lanes over the right keypoints: row-band test (the reference's vRowIndices table, :912-930, restated as
+//      floor(yR - r) <= (int)yL <= ceil(yR + r), r = 2*scale[octR]), octave window, disparity window, Hamming;
+//      wave minimum of (dist << 16 | iR) = first minimum in iR order (:966);
+//   2. 11x11 SAD at 11 horizontal offsets on the two level images (lanes over the 121 pixels, DPP wave sums);
+//   3. parabola fit, disparity, depth in the reference's fp32 expressions (:1021-1047).
+// The median filter over the accepted matches (:1060-1073) needs a sort of <= N pairs and stays on the host.
+// ------------------------------------------------------------------------------------------------------------
+struct StereoParams {
+  const uint8_t *imgL0, *imgR0; size_t strideL0, strideR0;   // level 0 of the chosen frames
+  const uint8_t *pyrL, *pyrR;                                 // pyramid blocks of the chosen frames (levels >= 1)
+  int w[ORB_MAXL], h[ORB_MAXL], pitch[ORB_MAXL]; size_t off[ORB_MAXL];
+  float sf[ORB_MAXL], invsf[ORB_MAXL];
+  int nlevels, rows;
+  const float *kpL, *kpR;                                     // 7 floats per keypoint (mvKeys / mvKeysRight)
+  const uint32_t *descL, *descR;
+  int nL, nR;
+  float mb, mbf;
+  float *uRight, *depth; int32_t *sad;                        // per left keypoint; sad = -1: no match
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoParams S) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (iL >= S.nL) return;
+  const float uL = S.kpL[(size_t)iL * 7], vL = S.kpL[(size_t)iL * 7 + 1];
+  const int levelL = __float_as_int(S.kpL[(size_t)iL * 7 + 5]);
+  float outU = -1.0f, outD = -1.0f;
+  int outSad = -1;
+  const float minD = 0.f, maxD = S.mbf / S.mb;                // :933-935
+  const float minU = uL - maxD, maxU = uL - minD;
+  const int row = (int)vL;
+  uint32_t best = 0xffffffffu;
+  if (row >= 0 && row < S.rows && !(maxU < 0) && levelL >= 0 && levelL < S.nlevels) {
+    uint32_t dl[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) dl[t] = S.descL[(size_t)iL * 8 + t];
+    for (int iR = lane; iR < S.nR; iR += 64) {
+      const float uR = S.kpR[(size_t)iR * 7], yR = S.kpR[(size_t)iR * 7 + 1];
+      const int oR = __float_as_int(S.kpR[(size_t)iR * 7 + 5]);
+      const float r = 2.0f * S.sf[min(max(oR, 0), ORB_MAXL - 1)];
+      const int maxr = (int)ceilf(yR + r), minr = (int)floorf(yR - r);
+      if (row < minr || row > maxr) continue;
+      if (oR < levelL - 1 || oR > levelL + 1) continue;         // :954
+      if (!(uR >= minU && uR <= maxU)) continue;                // :959
+      int dist = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) dist += __popc(dl[t] ^ S.descR[(size_t)iR * 8 + t]);
+      if (dist < ORBM_TH_HIGH) best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict <
+    }
+  }
+  best = wave_min_key(best);
+  const int thOrbDist = (ORBM_TH_HIGH + ORBM_TH_LOW) / 2;
+  if (best != 0xffffffffu && (int)(best >> 16) < thOrbDist) {
+    const int bestIdxR = (int)(best & 0xffffu);
+    const float uR0 = S.kpR[(size_t)bestIdxR * 7];
+    const float scaleFactor = S.invsf[levelL];
+    const float scaleduL = roundf(uL * scaleFactor), scaledvL = roundf(vL * scaleFactor), scaleduR0 = roundf(uR0 * scaleFactor);
+    constexpr int w = 5, L = 5;
+    const int lw = S.w[levelL], lh = S.h[levelL];
+    const int cuL = (int)scaleduL, cvL = (int)scaledvL, cuR = (int)scaleduR0;
+    const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+    // cv::Mat::rowRange / colRange throw outside the matrix: such keypoints are skipped (same rule in the test oracle)
+    const bool inside = cvL - w >= 0 && cvL + w + 1 <= lh && cuL - w >= 0 && cuL + w + 1 <= lw && !(iniu < 0 || endu >= (float)lw) && cuR - L - w >= 0;
+    if (inside) {
+      const uint8_t *IL, *IR;
+      int pL, pR;
+      if (levelL == 0) { IL = S.imgL0; IR = S.imgR0; pL = (int)S.strideL0; pR = (int)S.strideR0; }
+      else { IL = S.pyrL + S.off[levelL]; IR = S.pyrR + S.off[levelL]; pL = pR = S.pitch[levelL]; }
+      const int cL = IL[(size_t)cvL * pL + cuL];
+      // my pixels of the 11x11 window: p = lane and lane + 64
+      const int p0 = lane, p1 = lane + 64;
+      const int y0 = p0 / 11 - w, x0 = p0 % 11 - w, y1 = p1 / 11 - w, x1 = p1 % 11 - w;
+      const bool has1 = p1 < 121;
+      const int a0 = (int)IL[(size_t)(cvL + y0) * pL + cuL + x0] - cL;
+      const int a1 = has1 ? (int)IL[(size_t)(cvL + y1) * pL + cuL + x1] - cL : 0;
+      int sadv[2 * L + 1];
+#pragma unroll
+      for (int k = 0; k <= 2 * L; k++) {
+        const int incR = k - L;
+        const int cR = IR[(size_t)cvL * pR + cuR + incR];
+        const int b0 = (int)IR[(size_t)(cvL + y0) * pR + cuR + incR + x0] - cR;
+        const int b1 = has1 ? (int)IR[(size_t)(cvL + y1) * pR + cuR + incR + x1] - cR : 0;
+        sadv[k] = wave_sum_i32(abs(a0 - b0) + (has1 ? abs(a1 - b1) : 0));
+      }
+      int bestSad = 0x7fffffff, bestincR = 0;
+#pragma unroll
+      for (int k = 0; k <= 2 * L; k++)
+        if ((float)sadv[k] < (float)bestSad) { bestSad = sadv[k]; bestincR = k - L; }       // :1006
+      if (!(bestincR == -L || bestincR == L)) {
+        float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+        for (int k = 1; k < 2 * L; k++)
+          if (k == bestincR + L) { dist1 = (float)sadv[k - 1]; dist2 = (float)sadv[k]; dist3 = (float)sadv[k + 1]; }
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));    // :1024
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR = S.sf[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);       // :1030
+          float disparity = uL - bestuR;
+          if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }
+            outD = S.mbf / disparity;
+            outU = bestuR;
+            outSad = bestSad;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) { S.uRight[iL] = outU; S.depth[iL] = outD; S.sad[iL] = outSad; }
+}
+

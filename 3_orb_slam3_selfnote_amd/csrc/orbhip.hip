@@ -1452,6 +1452,71 @@ int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm
   return nmatches;
 }
 
+int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r, int nL, const orbx_keypoint_t *keysL,
+                                const uint8_t *descL, int nR, const orbx_keypoint_t *keysR, const uint8_t *descR, float mb, float mbf,
+                                float *uRight, float *depth) {
+  if (!hl || !hr || nL < 0 || nR < 0 || !uRight || !depth) return ORBX_E_ARG;
+  if (!hl->have_last || !hr->have_last) { hl->err = "orbx_compute_stereo_matches: extract both images first"; return ORBX_E_ARG; }
+  if (frame_l < 0 || frame_l >= hl->last.nframes || frame_r < 0 || frame_r >= hr->last.nframes) return ORBX_E_ARG;
+  if (hl->device != hr->device || hl->rows != hr->rows || hl->cols != hr->cols || hl->nlevels != hr->nlevels) {
+    hl->err = "orbx_compute_stereo_matches: the two extractors must share device, image size and pyramid";
+    return ORBX_E_ARG;
+  }
+  for (int i = 0; i < nL; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }   // Frame.cc:903-904
+  if (nL == 0 || nR == 0) return 0;
+  if (!keysL || !descL || !keysR || !descR || nR > 65535) return ORBX_E_ARG;
+  if (!(mb > 0.f)) return ORBX_E_ARG;
+  XCHECK(hl, hipSetDevice(hl->device));
+  hipStream_t s = hl->stream;
+  XCHECK(hl, hipStreamSynchronize(hr->stream));
+  DevBuf bufs[7];
+  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 7; i++) b[i].release(); } } guard{bufs};
+  const size_t sz[7] = {sizeof(orbx_keypoint_t) * (size_t)nL, sizeof(orbx_keypoint_t) * (size_t)nR, 32 * (size_t)nL, 32 * (size_t)nR,
+                        sizeof(float) * (size_t)nL, sizeof(float) * (size_t)nL, sizeof(int32_t) * (size_t)nL};
+  const void *src[4] = {keysL, keysR, descL, descR};
+  for (int i = 0; i < 7; i++) XCHECK(hl, bufs[i].reserve(sz[i]));
+  for (int i = 0; i < 4; i++) XCHECK(hl, hipMemcpyAsync(bufs[i].p, src[i], sz[i], hipMemcpyHostToDevice, s));
+  StereoParams S;
+  memset(&S, 0, sizeof(S));
+  S.imgL0 = hl->last.img0 + (size_t)frame_l * hl->last.img0_frame_stride; S.strideL0 = hl->last.img0_stride;
+  S.imgR0 = hr->last.img0 + (size_t)frame_r * hr->last.img0_frame_stride; S.strideR0 = hr->last.img0_stride;
+  S.pyrL = hl->last.pyr + (size_t)frame_l * hl->last.pyr_fs;
+  S.pyrR = hr->last.pyr + (size_t)frame_r * hr->last.pyr_fs;
+  for (int l = 0; l < hl->nlevels; l++) {
+    const LevelGeom &G = hl->geom[l];
+    S.w[l] = G.w; S.h[l] = G.h; S.pitch[l] = G.pitch; S.off[l] = G.off;
+    S.sf[l] = hl->mvScaleFactor[l]; S.invsf[l] = hl->mvInvScaleFactor[l];
+  }
+  S.nlevels = hl->nlevels; S.rows = hl->rows;
+  S.kpL = (const float *)bufs[0].p; S.kpR = (const float *)bufs[1].p;
+  S.descL = (const uint32_t *)bufs[2].p; S.descR = (const uint32_t *)bufs[3].p;
+  S.nL = nL; S.nR = nR; S.mb = mb; S.mbf = mbf;
+  S.uRight = (float *)bufs[4].p; S.depth = (float *)bufs[5].p; S.sad = (int32_t *)bufs[6].p;
+  hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, s, S);
+  XCHECK(hl, hipGetLastError());
+  std::vector<int32_t> sad((size_t)nL);
+  XCHECK(hl, hipMemcpyAsync(uRight, bufs[4].p, sz[4], hipMemcpyDeviceToHost, s));
+  XCHECK(hl, hipMemcpyAsync(depth, bufs[5].p, sz[5], hipMemcpyDeviceToHost, s));
+  XCHECK(hl, hipMemcpyAsync(sad.data(), bufs[6].p, sz[6], hipMemcpyDeviceToHost, s));
+  XCHECK(hl, hipStreamSynchronize(s));
+  // median filter over the accepted matches, Frame.cc:1060-1073 (an empty set - where the reference indexes an empty
+  // vector - is defined as "nothing to do")
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int i = 0; i < nL; i++)
+    if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+  if (!vDistIdx.empty()) {
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+      if ((float)vDistIdx[i].first < thDist) break;
+      uRight[vDistIdx[i].second] = -1;
+      depth[vDistIdx[i].second] = -1;
+    }
+  }
+  return 0;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

@@ -111,6 +111,17 @@ int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *s
 float orbx_ref_cosf(float x);
 float orbx_ref_sinf(float x);
 
+/* void Frame::ComputeStereoMatches()  (Frame.cc:901-1079), rectified stereo - the consumer of mvImagePyramid.
+ * left / right: the two extractors (mpORBextractorLeft / Right) AFTER orbx_extract / orbx_extract_batch_device of the
+ * two images: their pyramids are still on the device (frame_l / frame_r = index in their last batch), so no image
+ * crosses PCIe again.  keysL / descL, keysR / descR = mvKeys / mDescriptors, mvKeysRight / mDescriptorsRight (host);
+ * mb, mbf = Frame::mb, mbf.  uRight[nL], depth[nL] (out) = mvuRight, mvDepth.  The descriptor search, the 11x11 SAD
+ * refinement and the parabola fit run on the device (one wavefront per left keypoint); the median filter over the
+ * accepted matches (:1060-1073) needs a sort and runs on the host.  Returns 0. */
+int orbx_compute_stereo_matches(orbx_t *left, int frame_l, orbx_t *right, int frame_r, int nL, const orbx_keypoint_t *keysL,
+                                const uint8_t *descL, int nR, const orbx_keypoint_t *keysR, const uint8_t *descR, float mb,
+                                float mbf, float *uRight, float *depth);
+
 /* ---- ORBmatcher -------------------------------------------------------------------------------------------- */
 
 #define ORBM_TH_HIGH 100 /* ORBmatcher.cc:36 */

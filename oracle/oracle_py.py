@@ -79,6 +79,8 @@ def lib():
         _lib.orc_search_by_projection_ff_fisheye.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p] +
                                                              [C.c_float] * 2 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
         _lib.orc_search_for_initialization.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        _lib.orc_compute_stereo_matches.argtypes = ([C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 +
+                                                    [C.c_float, C.c_float, C.c_void_p, C.c_void_p])
         _lib.orc_frame_init.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p, C.c_int]
     return _lib
 
@@ -124,6 +126,21 @@ class OracleExtractor:
         arr = (C.c_void_p * self.nlevels)(*[_p(a) for a in levels])
         self.L.orc_compute_pyramid(C.byref(self.e), _p(img), cols, rows, C.c_size_t(img.strides[0]), arr)
         return levels
+
+    def compute_stereo_matches(self, imgL, imgR, keysL, descL, keysR, descR, mb, mbf):
+        """Frame::ComputeStereoMatches (Frame.cc:901-1079) on the two rectified images; returns (mvuRight, mvDepth)."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        lvL, lvR = self.pyramid(imgL), self.pyramid(imgR)
+        arrL = (C.c_void_p * self.nlevels)(*[_p(x) for x in lvL])
+        arrR = (C.c_void_p * self.nlevels)(*[_p(x) for x in lvR])
+        rows, cols = imgL.shape
+        nL, nR = len(keysL), len(keysR)
+        uR, depth = np.zeros(nL, np.float32), np.zeros(nL, np.float32)
+        args = [a(keysL["x"], np.float32), a(keysL["y"], np.float32), a(keysL["octave"], np.int32), a(descL, np.uint8)]
+        argsR = [a(keysR["x"], np.float32), a(keysR["y"], np.float32), a(keysR["octave"], np.int32), a(descR, np.uint8)]
+        self.L.orc_compute_stereo_matches(C.byref(self.e), arrL, arrR, cols, rows, nL, *[_p(x) for x in args], nR, *[_p(x) for x in argsR],
+                                          C.c_float(mb), C.c_float(mbf), _p(uR), _p(depth))
+        return uR, depth
 
     def level_candidates(self, level_img):
         level_img = np.ascontiguousarray(level_img, dtype=np.uint8)

@@ -1292,6 +1292,122 @@ int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* N1: Frame::ComputeStereoMatches, Frame.cc:901-1079 (rectified stereo).                          */
+/* levelsL / levelsR: pyramid ROIs (mvImagePyramid of the two extractors), level l has size          */
+/* orc_level_size(l) and stride = its width.  kx/ky/oct = mvKeys / mvKeysRight.                       */
+/* cv::Mat::rowRange / colRange throw outside the matrix; such keypoints are skipped here (defined). */
+/* With no accepted match the reference indexes an empty vector (:1062); defined as "nothing to do". */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int dist; int idx; } orc_distidx;
+static int cmp_distidx(const void *a, const void *b) {
+  const orc_distidx *x = (const orc_distidx *)a, *y = (const orc_distidx *)b;
+  if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+void orc_compute_stereo_matches(const orc_extractor *e, uint8_t *const *levelsL, uint8_t *const *levelsR, int cols, int rows,
+                                int N, const float *kxL, const float *kyL, const int32_t *octL, const uint8_t *descL,
+                                int Nr, const float *kxR, const float *kyR, const int32_t *octR, const uint8_t *descR,
+                                float mb, float mbf, float *mvuRight, float *mvDepth) {
+  for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+  const int thOrbDist = (100 + 50) / 2;
+  const int nRows = rows;
+  /* row table, :912-930: CSR in push order */
+  int *cnt = (int *)calloc((size_t)nRows + 1, sizeof(int));
+  for (int iR = 0; iR < Nr; iR++) {
+    const float r = 2.0f * e->mvScaleFactor[octR[iR]];
+    const int maxr = (int)ceilf(kyR[iR] + r), minr = (int)floorf(kyR[iR] - r);
+    for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) cnt[yi + 1]++;
+  }
+  for (int y = 0; y < nRows; y++) cnt[y + 1] += cnt[y];
+  int *rowIdx = (int *)malloc(sizeof(int) * (size_t)(cnt[nRows] + 1));
+  int *fill = (int *)calloc((size_t)nRows + 1, sizeof(int));
+  for (int iR = 0; iR < Nr; iR++) {
+    const float r = 2.0f * e->mvScaleFactor[octR[iR]];
+    const int maxr = (int)ceilf(kyR[iR] + r), minr = (int)floorf(kyR[iR] - r);
+    for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) rowIdx[cnt[yi] + fill[yi]++] = iR;
+  }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  orc_distidx *vDistIdx = (orc_distidx *)malloc(sizeof(orc_distidx) * (size_t)(N + 1));
+  int nDI = 0;
+  for (int iL = 0; iL < N; iL++) {
+    const int levelL = octL[iL];
+    const float vL = kyL[iL], uL = kxL[iL];
+    const int row = (int)vL;
+    if (row < 0 || row >= nRows) continue;
+    const int c0 = cnt[row], c1 = cnt[row + 1];
+    if (c0 == c1) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = 100; /* TH_HIGH */
+    int bestIdxR = 0;
+    const uint8_t *dL = descL + 32 * (size_t)iL;
+    for (int k = c0; k < c1; k++) {
+      const int iR = rowIdx[k];
+      if (octR[iR] < levelL - 1 || octR[iR] > levelL + 1) continue;
+      const float uR = kxR[iR];
+      if (uR >= minU && uR <= maxU) {
+        const int dist = orc_descriptor_distance(dL, descR + 32 * (size_t)iR);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = kxR[bestIdxR];
+      const float scaleFactor = e->mvInvScaleFactor[levelL];
+      const float scaleduL = roundf(uL * scaleFactor), scaledvL = roundf(vL * scaleFactor), scaleduR0 = roundf(uR0 * scaleFactor);
+      const int w = 5, L = 5;
+      int lw, lh;
+      orc_level_size(e, levelL, cols, rows, &lw, &lh);
+      const int cuL = (int)scaleduL, cvL = (int)scaledvL, cuR = (int)scaleduR0;
+      if (cvL - w < 0 || cvL + w + 1 > lh || cuL - w < 0 || cuL + w + 1 > lw) continue;   /* rowRange/colRange would throw */
+      const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= (float)lw) continue;
+      if (cuR - L - w < 0) continue;                                                     /* colRange would throw */
+      const uint8_t *IL = levelsL[levelL], *IRm = levelsR[levelL];
+      const int cL = IL[(size_t)cvL * lw + cuL];
+      int bestSad = 2147483647, bestincR = 0;
+      float vDists[11];
+      for (int incR = -L; incR <= L; incR++) {
+        const int cR = IRm[(size_t)cvL * lw + cuR + incR];
+        int sad = 0;
+        for (int py = -w; py <= w; py++)
+          for (int px = -w; px <= w; px++) {
+            const int a = (int)IL[(size_t)(cvL + py) * lw + cuL + px] - cL;
+            const int b = (int)IRm[(size_t)(cvL + py) * lw + cuR + incR + px] - cR;
+            sad += abs(a - b);
+          }
+        const float dist = (float)sad;
+        if (dist < (float)bestSad) { bestSad = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = e->mvScaleFactor[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx[nDI].dist = bestSad; vDistIdx[nDI].idx = iL; nDI++;
+      }
+    }
+  }
+  if (nDI > 0) {
+    qsort(vDistIdx, (size_t)nDI, sizeof(orc_distidx), cmp_distidx);
+    const float median = (float)vDistIdx[nDI / 2].dist;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = nDI - 1; i >= 0; i--) {
+      if ((float)vDistIdx[i].dist < thDist) break;
+      mvuRight[vDistIdx[i].idx] = -1;
+      mvDepth[vDistIdx[i].idx] = -1;
+    }
+  }
+  free(cnt); free(rowIdx); free(fill); free(vDistIdx);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* N2: ORBmatcher::SearchForInitialization, ORBmatcher.cc:722-837                                 */
 /* F1 side: octave / angle / descriptors of mvKeysUn; F2 = orc_frame; prevMatched[2*n1] in/out.    */
 /* ------------------------------------------------------------------------------------------ */

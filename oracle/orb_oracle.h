@@ -169,6 +169,12 @@ int orc_search_by_projection_ff_fisheye(orc_frame *cl, orc_frame *cr, int nLast,
                                         int camType, const float *camParams, float mb, float th, int bMono, int checkOri,
                                         int32_t *slot, uint8_t *slot_obs);
 
+/* N1: Frame::ComputeStereoMatches, Frame.cc:901-1079. */
+void orc_compute_stereo_matches(const orc_extractor *e, uint8_t *const *levelsL, uint8_t *const *levelsR, int cols, int rows,
+                                int N, const float *kxL, const float *kyL, const int32_t *octL, const uint8_t *descL,
+                                int Nr, const float *kxR, const float *kyR, const int32_t *octR, const uint8_t *descR,
+                                float mb, float mbf, float *mvuRight, float *mvDepth);
+
 /* N2: ORBmatcher::SearchForInitialization, ORBmatcher.cc:722-837. */
 int orc_search_for_initialization(int n1, const int32_t *octave1, const float *angle1, const uint8_t *desc1, orc_frame *F2,
                                   float *prevMatched, int windowSize, float nnratio, int checkOri, int32_t *vnMatches12);

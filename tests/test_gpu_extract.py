@@ -227,3 +227,27 @@ def test_extract_parity_config_matrix(pkg, oracle, synth, cfg):
     for l in range(nl):
         assert np.array_equal(e.image_pyramid_level(l), pyr[l])
     e.close()
+
+
+@pytest.mark.parametrize("disp", [12, 37])
+def test_compute_stereo_matches_n1(pkg, oracle, synth, disp):
+    """Frame::ComputeStereoMatches (Frame.cc:901-1079): right image = the same scene shifted by `disp` px, both images
+    extracted on the device (their pyramids stay resident), descriptor search + 11x11 SAD + parabola on the device."""
+    big = synth.make_frame(4100 + disp, H=480, W=752 + 64)
+    imgL = np.ascontiguousarray(big[:, 0:752])                       # scene column c is at xL = c ...
+    imgR = np.ascontiguousarray(big[:, disp:disp + 752])             # ... and at xR = c - disp: disparity uL - uR = disp
+    exL, exR = pkg.ORBextractor(**EUROC), pkg.ORBextractor(**EUROC)
+    try:
+        _, kL, dL = exL(imgL, None, (0, 0))
+        _, kR, dR = exR(imgR, None, (0, 0))
+        mb, mbf = 0.11, 47.9
+        uR_gpu, z_gpu = exL.ComputeStereoMatches(exR, kL, dL, kR, dR, mb, mbf)
+        o = oracle.OracleExtractor(**EUROC)
+        uR_ref, z_ref = o.compute_stereo_matches(imgL, imgR, kL, dL, kR, dR, mb, mbf)
+        assert np.array_equal(uR_gpu.view(np.uint32), uR_ref.view(np.uint32))
+        assert np.array_equal(z_gpu.view(np.uint32), z_ref.view(np.uint32))
+        ok = uR_ref >= 0
+        assert ok.sum() > 200
+        assert np.median(np.abs((kL["x"][ok] - uR_ref[ok]) - disp)) < 1.0   # the recovered disparity is the shift
+    finally:
+        exL.close(); exR.close()
