@@ -12,6 +12,7 @@
 //   int  ORBmatcher::SearchByProjection(Frame &Cur, KeyFrame *pKF, const set<MapPoint*>&, float th, int ORBdist)       :2291-2413
 //   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool, bool) :981-1222
 //   int  ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f>&, vector<int>&, int windowSize)  :722-837
+//   int  ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)                          :273-469
 //   int  ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)                                                  :2463-2483
 //   void ORBmatcher::ComputeThreeMaxima(vector<int>*, int, int&, int&, int&)                                             :2416-2458
 //   float ORBmatcher::RadiusByViewingCos(const float&)                                                                   :216-222
@@ -269,6 +270,40 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
   if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
   for (int i = 0; i < CurrentFrame.N; i++)
     if (slot[i] >= 0 && slot[i] < nKF) CurrentFrame.mvpMapPoints[i] = vpMPs[slot[i]];  // :2373
+  return n;
+}
+
+int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
+  if (F.Nleft != -1 || pKF->mpCamera2) return SearchByBoW_ref(pKF, F, vpMapPointMatches);  // two-camera rigs: reference path
+  const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+  vpMapPointMatches.assign(F.N, static_cast<MapPoint *>(NULL));  // :277
+  struct Flat { std::vector<uint8_t> has; std::vector<uint32_t> id; std::vector<int32_t> start, idx; orbm_keyframe_t k; };
+  auto flatten = [](const DBoW2::FeatureVector &fv, Flat &X) {
+    X.start.push_back(0);
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+      X.id.push_back(it->first);
+      for (unsigned v : it->second) X.idx.push_back((int32_t)v);
+      X.start.push_back((int32_t)X.idx.size());
+    }
+    X.k.n_nodes = (int32_t)X.id.size();
+    X.k.node_id = X.id.data(); X.k.node_start = X.start.data(); X.k.node_idx = X.idx.data();
+    X.k.u_right = nullptr; X.k.scale_factors = nullptr; X.k.level_sigma2 = nullptr; X.k.nlevels = 0;
+  };
+  Flat A, B;
+  flatten(pKF->mFeatVec, A);
+  flatten(F.mFeatVec, B);
+  A.has.resize(pKF->N);
+  for (int i = 0; i < pKF->N; i++) A.has[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();  // :307-313
+  A.k.n = pKF->N; A.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(pKF->mvKeysUn.data());
+  A.k.descriptors = pKF->mDescriptors.data; A.k.has_mappoint = A.has.data();
+  B.has.assign(F.N, 0);
+  B.k.n = F.N; B.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(F.mvKeys.data());  // angle of F.mvKeys, :395
+  B.k.descriptors = F.mDescriptors.data; B.k.has_mappoint = B.has.data();
+  std::vector<int32_t> mF(F.N, -1);
+  const int n = orbm_search_by_bow(matcher(), &A.k, &B.k, mfNNratio, mbCheckOrientation ? 1 : 0, mF.data());
+  if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
+  for (int i = 0; i < F.N; i++)
+    if (mF[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[mF[i]];  // :389
   return n;
 }
 

@@ -850,6 +850,61 @@ __global__ __launch_bounds__(256) void k_triangulation_match(TriParams T) {
   if (lane == 0) T.matches12[idx1] = best != 0xffffffffu ? T.node_idx2[item.start2 + (0xffff - (int)(best & 0xffff))] : -1;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) inner loops (ORBmatcher.cc:303-438, Nleft == -1): the
+// keypoints of the frame that fall into a vocabulary node can only be taken by keyframe keypoints of the same node, so
+// the shared nodes are independent problems: one wavefront per shared node.  It walks the node's keyframe keypoints
+// in order (:303); lanes hold the node's frame keypoints (position p = lane + 64 t, "taken" bit t in a lane register);
+// best / second = two wave minima of (dist << 16 | position) - strict `<`, first minimum in position order (:326-335);
+// accept rule :385-387, the taken frame keypoint is skipped by the rest of the node (:321).
+struct BowItem { int32_t startKF, lenKF, startF, lenF; };
+struct BowParams {
+  const uint32_t *descKF, *descF;
+  const uint8_t *hasmpKF;                 // pMP && !pMP->isBad()
+  const int32_t *node_idxKF, *node_idxF;
+  const BowItem *items; int nitems;
+  float nnratio;
+  int32_t *matchF;                        // [F.N] keyframe keypoint index or -1 (pre-filled with -1)
+};
+
+__global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
+  const int lane = threadIdx.x & 63;
+  const int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (it >= B.nitems) return;
+  const BowItem item = B.items[it];
+  const int nt = (item.lenF + 63) >> 6;     // <= 32 (host splits nothing: larger nodes are refused there)
+  uint32_t taken = 0;
+  for (int k = 0; k < item.lenKF; k++) {
+    const int idxKF = B.node_idxKF[item.startKF + k];
+    if (!B.hasmpKF[idxKF]) continue;                                 // :307-313
+    uint32_t dk[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) dk[w] = B.descKF[(size_t)idxKF * 8 + w];
+    uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
+    for (int t = 0; t < nt; t++) {
+      const int pos = lane + 64 * t;
+      if (pos < item.lenF && !((taken >> t) & 1u)) {                 // :321
+        const int idxF = B.node_idxF[item.startF + pos];
+        int dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) dist += __popc(dk[w] ^ B.descF[(size_t)idxF * 8 + w]);
+        const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)pos;
+        if (key < b1) { b2 = b1; b1 = key; }
+        else if (key < b2) b2 = key;
+      }
+    }
+    const uint32_t g1 = wave_min_key(b1);
+    const uint32_t g2 = wave_min_key(b1 == g1 ? b2 : b1);
+    const int bestDist1 = g1 != 0xffffffffu ? (int)(g1 >> 16) : 256, bestDist2 = g2 != 0xffffffffu ? (int)(g2 >> 16) : 256;
+    if (bestDist1 <= ORBM_TH_LOW && (float)bestDist1 < B.nnratio * (float)bestDist2) {   // :385-387
+      const int pos = (int)(g1 & 0xffffu);
+      if (lane == (pos & 63)) {
+        taken |= 1u << (pos >> 6);
+        B.matchF[B.node_idxF[item.startF + pos]] = idxKF;            // :389
+      }
+    }
+  }
+}
+
 // K8 brute force: dist[i][j] = popcount(q_i ^ c_j).  Candidates staged through LDS in 256-descriptor (8 KB) chunks.
 __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t *q, int nq, const uint32_t *c, int nc, uint16_t *dist) {
   __shared__ uint32_t sC[256 * 9];  // +1 word pad per descriptor: conflict-free column reads

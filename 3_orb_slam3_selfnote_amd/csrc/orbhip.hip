@@ -1517,6 +1517,78 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
   return 0;
 }
 
+int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF) {
+  if (!m || !kf || !f || !matchF || kf->n < 0 || f->n < 0) return ORBX_E_ARG;
+  for (int i = 0; i < f->n; i++) matchF[i] = -1;                  // :277
+  if (kf->n == 0 || f->n == 0 || kf->n_nodes <= 0 || f->n_nodes <= 0) return 0;
+  if (!kf->descriptors || !f->descriptors || !kf->has_mappoint || !kf->node_id || !f->node_id || !kf->node_start || !f->node_start ||
+      !kf->node_idx || !f->node_idx || !kf->keys_un || !f->keys_un) return ORBX_E_ARG;
+  // merge-walk of the two feature vectors (:292-296, :440-447): one work item per shared node
+  std::vector<BowItem> items;
+  int a = 0, b = 0;
+  while (a < kf->n_nodes && b < f->n_nodes) {
+    if (kf->node_id[a] == f->node_id[b]) {
+      const int lk = kf->node_start[a + 1] - kf->node_start[a], lf = f->node_start[b + 1] - f->node_start[b];
+      if (lf > 2048) { m->err = "SearchByBoW: more than 2048 frame keypoints in one vocabulary node"; return ORBX_E_ARG; }
+      if (lk > 0 && lf > 0) items.push_back(BowItem{kf->node_start[a], lk, f->node_start[b], lf});
+      a++; b++;
+    } else if (kf->node_id[a] < f->node_id[b]) {
+      while (a < kf->n_nodes && kf->node_id[a] < f->node_id[b]) a++;   // lower_bound
+    } else {
+      while (b < f->n_nodes && f->node_id[b] < kf->node_id[a]) b++;
+    }
+  }
+  if (items.empty()) return 0;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const size_t nidxKF = (size_t)kf->node_start[kf->n_nodes], nidxF = (size_t)f->node_start[f->n_nodes];
+  DevBuf bufs[7];
+  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 7; i++) b[i].release(); } } guard{bufs};
+  const size_t sz[7] = {32 * (size_t)kf->n, 32 * (size_t)f->n, (size_t)kf->n, sizeof(int32_t) * nidxKF, sizeof(int32_t) * nidxF,
+                        sizeof(BowItem) * items.size(), sizeof(int32_t) * (size_t)f->n};
+  const void *src[7] = {kf->descriptors, f->descriptors, kf->has_mappoint, kf->node_idx, f->node_idx, items.data(), matchF};
+  for (int i = 0; i < 7; i++) {
+    MCHECK(m, bufs[i].reserve(std::max<size_t>(sz[i], 4)));
+    MCHECK(m, hipMemcpyAsync(bufs[i].p, src[i], sz[i], hipMemcpyHostToDevice, s));
+  }
+  BowParams B;
+  B.descKF = (const uint32_t *)bufs[0].p; B.descF = (const uint32_t *)bufs[1].p; B.hasmpKF = (const uint8_t *)bufs[2].p;
+  B.node_idxKF = (const int32_t *)bufs[3].p; B.node_idxF = (const int32_t *)bufs[4].p;
+  B.items = (const BowItem *)bufs[5].p; B.nitems = (int)items.size();
+  B.nnratio = nnratio; B.matchF = (int32_t *)bufs[6].p;
+  hipLaunchKernelGGL(k_bow_match, dim3((B.nitems + 3) / 4), dim3(256), 0, s, B);
+  MCHECK(m, hipGetLastError());
+  MCHECK(m, hipMemcpyAsync(matchF, bufs[6].p, sz[6], hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  int nmatches = 0;
+  for (int i = 0; i < f->n; i++) nmatches += matchF[i] >= 0 ? 1 : 0;
+  if (!checkOri) return nmatches;
+  // rotation histogram in the reference's push order (:303, node by node, keyframe keypoints in node order), :391-404, :451-466
+  std::vector<int32_t> fOfKF((size_t)kf->n, -1);
+  for (int i = 0; i < f->n; i++) if (matchF[i] >= 0) fOfKF[matchF[i]] = i;
+  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+  const float factor = 1.0f / ORBM_HISTO_LENGTH;
+  for (const BowItem &itx : items)
+    for (int k = 0; k < itx.lenKF; k++) {
+      const int idxKF = kf->node_idx[itx.startKF + k];
+      const int idxF = fOfKF[idxKF];
+      if (idxF < 0) continue;
+      float rot = kf->keys_un[idxKF].angle - f->keys_un[idxF].angle;
+      if ((double)rot < 0.0) rot += 360.0f;
+      int bin = (int)roundf(rot * factor);
+      if (bin == ORBM_HISTO_LENGTH) bin = 0;
+      if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(idxF);
+    }
+  int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+  orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (int idx : rotHist[i]) { matchF[idx] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

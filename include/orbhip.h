@@ -296,6 +296,14 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *kf1, const o
 int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm_frame_t *f2, float *prev_matched,
                                    int window_size, float nnratio, int checkOri, int32_t *matches12);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)   (ORBmatcher.cc:273-469,
+ * Frame::Nleft == -1).  kf: the keyframe (has_mappoint[i] = pMP && !pMP->isBad(), keys_un = mvKeysUn for the angle);
+ * f: the frame in the same flattened form (keys_un = F.mvKeys, descriptors = F.mDescriptors, node_* = F.mFeatVec;
+ * u_right / has_mappoint / scale tables unused).  matchF[f->n] (out) = index of the keyframe keypoint whose map point
+ * the frame keypoint received (vpMapPointMatches[i] = vpMapPointsKF[matchF[i]]) or -1.  One wavefront per shared
+ * vocabulary node on the device; rotation histogram on the host.  Returns nmatches. */
+int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

@@ -1805,3 +1805,64 @@ void orc_image_bounds(int cols, int rows, const float *K, const float *D, int nD
     *minX = 0.0f; *maxX = (float)cols; *minY = 0.0f; *maxY = (float)rows;
   }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N3 (first member): ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&),           */
+/* ORBmatcher.cc:273-469, Frame::Nleft == -1.  Both sides as orc_keyframe (the frame's has_mp    */
+/* is unused); matchF[F.N] = keyframe keypoint index whose map point the frame keypoint got.    */
+/* ------------------------------------------------------------------------------------------ */
+int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF) {
+  const int HISTO_LENGTH = 30, TH_LOW = 50;
+  int nmatches = 0;
+  for (int i = 0; i < F->N; i++) matchF[i] = -1;
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(F->N + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < KF->n_nodes && b < F->n_nodes) {
+    if (KF->node_id[a] == F->node_id[b]) {
+      for (int iKF = KF->node_start[a]; iKF < KF->node_start[a + 1]; iKF++) {
+        const int realIdxKF = KF->node_idx[iKF];
+        if (!KF->has_mp[realIdxKF]) continue;
+        const uint8_t *dKF = KF->desc + 32 * (size_t)realIdxKF;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int iF = F->node_start[b]; iF < F->node_start[b + 1]; iF++) {
+          const int realIdxF = F->node_idx[iF];
+          if (matchF[realIdxF] >= 0) continue;
+          const int dist = orc_descriptor_distance(dKF, F->desc + 32 * (size_t)realIdxF);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+          if ((float)bestDist1 < nnratio * (float)bestDist2) {
+            matchF[bestIdxF] = realIdxKF;
+            if (checkOri) {
+              float rot = KF->angle[realIdxKF] - F->angle[bestIdxF];
+              if ((double)rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin][rotN[bin]++] = bestIdxF;
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (KF->node_id[a] < F->node_id[b]) {
+      while (a < KF->n_nodes && KF->node_id[a] < F->node_id[b]) a++;
+    } else {
+      while (b < F->n_nodes && F->node_id[b] < KF->node_id[a]) b++;
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < rotN[i]; j++) { matchF[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  return nmatches;
+}

@@ -195,6 +195,9 @@ typedef struct {
   const float *scaleFactors, *levelSigma2;
 } orc_keyframe;
 
+/* N3 (first member): SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ORBmatcher.cc:273-469 (Nleft == -1). */
+int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF);
+
 /* M6: SearchForTriangulation(KF1, KF2, F12, pairs, bOnlyStereo, bCoarse), ORBmatcher.cc:981-1222, both cameras
  * Pinhole and no second camera (mpCamera2 == NULL).  R?w row-major 3x3, t?w 3, Cw1 = pKF1->GetCameraCenter().
  * cam? = [fx, fy, cx, cy].  matches12[N1] out (vMatches12).  Returns nmatches. */

@@ -402,3 +402,28 @@ def test_search_for_initialization_n2(pkg, oracle, synth, nfeatures, window):
         assert total > 50
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("nodes,check_ori", [(128, True), (16, True), (128, False)])
+def test_search_by_bow_n3(pkg, oracle, synth, nodes, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:273-469): per vocabulary node, keyframe keypoints in
+    node order take the best unclaimed frame keypoint (best/second ratio, TH_LOW); rotation-histogram pruning.
+    nodes=16 gives nodes of more than 64 frame keypoints (several lane passes, many in-node claims)."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3800)
+    rng = np.random.default_rng(nodes)
+    sigma2 = (sf * sf).astype(np.float32)
+    mp0 = (rng.random(len(k0)) < 0.8).astype(np.uint8)               # keyframe keypoints that have a (good) map point
+    # descriptors that survive a frame step share a node: hash on bits of the KEYFRAME descriptor of the matching keypoint
+    fv0, fv1 = _bow(d0, nodes), _bow(d1, nodes)
+    KF = pkg.KeyFrameView(k0, d0, fv0, sf, sigma2, has_mappoint=mp0)
+    F = pkg.KeyFrameView(k1, d1, fv1, sf, sigma2)
+    OKF = oracle.OracleKeyFrame(k0, d0, fv0, sf, sigma2, has_mp=mp0)
+    OF = oracle.OracleKeyFrame(k1, d1, fv1, sf, sigma2)
+    m = pkg.ORBmatcher(0.7, check_ori)                                # Tracking.cc:2808: ORBmatcher matcher(0.7,true)
+    try:
+        n_gpu, m_gpu = m.SearchByBoW(KF, F)
+        n_ref, m_ref = oracle.search_by_bow(OKF, OF, 0.7, check_ori)
+        assert n_gpu == n_ref and n_ref > 100
+        assert np.array_equal(m_gpu, m_ref)
+    finally:
+        m.close()
