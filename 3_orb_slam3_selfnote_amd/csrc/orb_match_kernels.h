@@ -138,7 +138,8 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
 
 // STEREO: fisheye-stereo problem (image restriction per query, window-non-empty flags); the mono instantiation carries
 // none of that in its inner loop.
-template <typename KT, bool STEREO>
+// UR: the frame has mvuRight (rectified stereo / RGB-D): the right-coordinate test is compiled in.
+template <typename KT, bool STEREO, bool UR>
 __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
@@ -200,11 +201,13 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
         if (STEREO && wantAny) any = any || (sok && (fpass & ~(viol | ~(int)(cm.bits << 6))) < 0);  // GetFeaturesInArea alone (bit 25 = in grid)
         viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
         bool ok = sok && (fpass & ~viol) < 0;
-        if (w.stereo) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);   // ORBmatcher.cc:93-98, :2139-2146
+        if (UR) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);        // ORBmatcher.cc:93-98, :2139-2146
         if (ok) {
           const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-          const int dist = __popc(a.x ^ qd[0]) + __popc(a.y ^ qd[1]) + __popc(a.z ^ qd[2]) + __popc(a.w ^ qd[3]) +
-                           __popc(b.x ^ qd[4]) + __popc(b.y ^ qd[5]) + __popc(b.z ^ qd[6]) + __popc(b.w ^ qd[7]);
+          int dist = __popc(a.x ^ qd[0]);                                 // one accumulating v_bcnt per word
+          dist = __popc(a.y ^ qd[1]) + dist; dist = __popc(a.z ^ qd[2]) + dist; dist = __popc(a.w ^ qd[3]) + dist;
+          dist = __popc(b.x ^ qd[4]) + dist; dist = __popc(b.y ^ qd[5]) + dist; dist = __popc(b.z ^ qd[6]) + dist;
+          dist = __popc(b.w ^ qd[7]) + dist;
           K t = KT::make(dist, cell_of(cm.bits), base + c);
           if (t < top[MATCH_TOPK - 1]) {
 #pragma unroll

@@ -847,8 +847,9 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (lds > 48 * 1024)                                                                                                  \
       MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, true>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);       \
-    else hipLaunchKernelGGL((k_match_scan<KT, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
+    if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, true, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);      \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, false, true>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p); \
+    else hipLaunchKernelGGL((k_match_scan<KT, false, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);            \
     if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
