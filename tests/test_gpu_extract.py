@@ -251,3 +251,21 @@ def test_compute_stereo_matches_n1(pkg, oracle, synth, disp):
         assert np.median(np.abs((kL["x"][ok] - uR_ref[ok]) - disp)) < 1.0   # the recovered disparity is the shift
     finally:
         exL.close(); exR.close()
+
+
+def test_compute_stereo_matches_edge_cases(pkg, synth):
+    """No right keypoints -> all -1; calling before any extraction is an argument error, not a crash."""
+    img = synth.make_frame(4200)
+    exL, exR = pkg.ORBextractor(**EUROC), pkg.ORBextractor(**EUROC)
+    try:
+        with pytest.raises(pkg.OrbError):
+            exL.ComputeStereoMatches(exR, np.zeros(1, pkg.KP_DTYPE), np.zeros((1, 32), np.uint8), np.zeros(1, pkg.KP_DTYPE), np.zeros((1, 32), np.uint8), 0.11, 47.9)
+        _, kL, dL = exL(img, None, (0, 0))
+        _, kR, dR = exR(img, None, (0, 0))
+        uR, depth = exL.ComputeStereoMatches(exR, kL, dL, kR[:0], dR[:0], 0.11, 47.9)
+        assert (uR == -1).all() and (depth == -1).all()
+        # identical images: every SAD is 0, so the median is 0, thDist = 0 and the filter `first < thDist` (:1066) keeps nothing
+        uR, depth = exL.ComputeStereoMatches(exR, kL, dL, kR, dR, 0.11, 47.9)
+        assert (uR == -1).all() and (depth == -1).all()
+    finally:
+        exL.close(); exR.close()

@@ -427,3 +427,36 @@ def test_search_by_bow_n3(pkg, oracle, synth, nodes, check_ori):
         assert np.array_equal(m_gpu, m_ref)
     finally:
         m.close()
+
+
+def test_edge_cases_of_the_wider_api(pkg, oracle, synth, matcher):
+    """Empty / degenerate inputs of the members added after the core path: nothing to match must mean 0, not an error."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3900)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    sigma2 = (sf * sf).astype(np.float32)
+    # SearchForInitialization against an empty frame, and from an empty frame
+    F1, Fe = pkg.FrameView(k0, d0, bounds), pkg.FrameView(k0[:0], d0[:0], bounds)
+    prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32).copy()
+    n, m12 = matcher.SearchForInitialization(F1, Fe, prev, 100)
+    assert n == 0 and (m12 == -1).all()
+    n, m12 = matcher.SearchForInitialization(Fe, F1, np.zeros((0, 2), np.float32), 100)
+    assert n == 0 and len(m12) == 0
+    # SearchByBoW without a shared node / without map points
+    fvA = {3: list(range(len(k0)))}
+    fvB = {5: list(range(len(k1)))}
+    KF = pkg.KeyFrameView(k0, d0, fvA, sf, sigma2, has_mappoint=np.ones(len(k0), np.uint8))
+    Fr = pkg.KeyFrameView(k1, d1, fvB, sf, sigma2)
+    n, mF = matcher.SearchByBoW(KF, Fr)
+    assert n == 0 and (mF == -1).all()
+    KF0 = pkg.KeyFrameView(k0, d0, _bow(d0), sf, sigma2, has_mappoint=np.zeros(len(k0), np.uint8))
+    n, mF = matcher.SearchByBoW(KF0, pkg.KeyFrameView(k1, d1, _bow(d1), sf, sigma2))
+    assert n == 0 and (mF == -1).all()
+    # fisheye-stereo search with an empty right image and no partners
+    F = pkg.FrameView(k1, d1, bounds)
+    nmp = 50
+    z = np.zeros(nmp, np.float32)
+    lvl = k0["octave"][:nmp].astype(np.int32)
+    n, ml, mr = matcher.SearchByProjectionFisheye(F, len(k1), None, None, d0[:nmp], sf, 3.0, np.ones(nmp, np.uint8), k0["x"][:nmp] + np.float32(offs[0][0] - offs[1][0]),
+                                                  k0["y"][:nmp] + np.float32(offs[0][1] - offs[1][1]), np.ones(nmp, np.float32), lvl,
+                                                  np.ones(nmp, np.uint8), z, z, np.ones(nmp, np.float32), lvl)
+    assert (mr == -1).all() and n == int((ml >= 0).sum()) and n > 10
