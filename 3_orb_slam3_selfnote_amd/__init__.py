@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -118,6 +118,7 @@ def load(build_if_needed=True):
                                                                i32, i32, vp, vp]
     L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
+    L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
     L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
@@ -541,6 +542,17 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_search_by_bow rc=%d" % rc)
         return rc, m[:F.N]
+
+    def SearchByBoWKeyFrames(self, KF1, KF2):
+        """SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) -- ORBmatcher.cc:839-979.
+        Returns (nmatches, matches12[KF1.N] = keypoint index in KF2 or -1)."""
+        m = np.full(max(KF1.N, 1), -1, dtype=np.int32)
+        a, b = KF1.struct(), KF2.struct()
+        rc = self.L.orbm_search_by_bow_keyframes(self.m, C.byref(a), C.byref(b), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m))
+        self._check(rc, "orbm_search_by_bow_keyframes")
+        if rc < 0:
+            raise OrbError("orbm_search_by_bow_keyframes rc=%d" % rc)
+        return rc, m[:KF1.N]
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

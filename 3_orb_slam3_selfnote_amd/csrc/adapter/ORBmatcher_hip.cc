@@ -13,6 +13,7 @@
 //   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool, bool) :981-1222
 //   int  ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f>&, vector<int>&, int windowSize)  :722-837
 //   int  ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)                          :273-469
+//   int  ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)                         :839-979
 //   int  ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)                                                  :2463-2483
 //   void ORBmatcher::ComputeThreeMaxima(vector<int>*, int, int&, int&, int&)                                             :2416-2458
 //   float ORBmatcher::RadiusByViewingCos(const float&)                                                                   :216-222
@@ -304,6 +305,37 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
   if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
   for (int i = 0; i < F.N; i++)
     if (mF[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[mF[i]];  // :389
+  return n;
+}
+
+int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) {
+  if (pKF1->NLeft != -1 || pKF2->NLeft != -1) return SearchByBoW_ref(pKF1, pKF2, vpMatches12);  // two-camera rigs: reference path
+  const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+  vpMatches12.assign(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));  // :852
+  struct Flat { std::vector<uint8_t> has; std::vector<uint32_t> id; std::vector<int32_t> start, idx; orbm_keyframe_t k; };
+  auto flatten = [](KeyFrame *pKF, const std::vector<MapPoint *> &mps, Flat &X) {
+    X.start.push_back(0);
+    for (DBoW2::FeatureVector::const_iterator it = pKF->mFeatVec.begin(); it != pKF->mFeatVec.end(); ++it) {
+      X.id.push_back(it->first);
+      for (unsigned v : it->second) X.idx.push_back((int32_t)v);
+      X.start.push_back((int32_t)X.idx.size());
+    }
+    X.has.resize(pKF->N);
+    for (int i = 0; i < pKF->N; i++) X.has[i] = mps[i] && !mps[i]->isBad();
+    X.k.n = pKF->N; X.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(pKF->mvKeysUn.data());
+    X.k.descriptors = pKF->mDescriptors.data; X.k.has_mappoint = X.has.data();
+    X.k.n_nodes = (int32_t)X.id.size();
+    X.k.node_id = X.id.data(); X.k.node_start = X.start.data(); X.k.node_idx = X.idx.data();
+    X.k.u_right = nullptr; X.k.scale_factors = nullptr; X.k.level_sigma2 = nullptr; X.k.nlevels = 0;
+  };
+  Flat A, B;
+  flatten(pKF1, vpMapPoints1, A);
+  flatten(pKF2, vpMapPoints2, B);
+  std::vector<int32_t> m12(pKF1->N, -1);
+  const int n = orbm_search_by_bow_keyframes(matcher(), &A.k, &B.k, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data());
+  if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
+  for (int i = 0; i < pKF1->N; i++)
+    if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];  // :927
   return n;
 }
 

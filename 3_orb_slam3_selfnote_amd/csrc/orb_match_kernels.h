@@ -867,6 +867,10 @@ struct BowParams {
   const BowItem *items; int nitems;
   float nnratio;
   int32_t *matchF;                        // [F.N] keyframe keypoint index or -1 (pre-filled with -1)
+  // SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:839-979) runs on the same kernel with: hasmpF = the second
+  // keyframe's keypoints that may be taken (:896-903), strict = accept needs bestDist1 < TH_LOW (:923, not <=),
+  // match12[KF.N] = taken keypoint of the second keyframe per keypoint of the first (:927); all 0 / NULL otherwise
+  const uint8_t *hasmpF; int strict; int32_t *match12;
 };
 
 __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
@@ -887,6 +891,7 @@ __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
       const int pos = lane + 64 * t;
       if (pos < item.lenF && !((taken >> t) & 1u)) {                 // :321
         const int idxF = B.node_idxF[item.startF + pos];
+        if (B.hasmpF && !B.hasmpF[idxF]) continue;                     // :896-903
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(dk[w] ^ B.descF[(size_t)idxF * 8 + w]);
@@ -898,11 +903,13 @@ __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
     const uint32_t g1 = wave_min_key(b1);
     const uint32_t g2 = wave_min_key(b1 == g1 ? b2 : b1);
     const int bestDist1 = g1 != 0xffffffffu ? (int)(g1 >> 16) : 256, bestDist2 = g2 != 0xffffffffu ? (int)(g2 >> 16) : 256;
-    if (bestDist1 <= ORBM_TH_LOW && (float)bestDist1 < B.nnratio * (float)bestDist2) {   // :385-387
+    if ((B.strict ? bestDist1 < ORBM_TH_LOW : bestDist1 <= ORBM_TH_LOW) && (float)bestDist1 < B.nnratio * (float)bestDist2) {   // :385-387
       const int pos = (int)(g1 & 0xffffu);
       if (lane == (pos & 63)) {
         taken |= 1u << (pos >> 6);
-        B.matchF[B.node_idxF[item.startF + pos]] = idxKF;            // :389
+        const int idxF = B.node_idxF[item.startF + pos];
+        if (B.matchF) B.matchF[idxF] = idxKF;                          // :389
+        if (B.match12) B.match12[idxKF] = idxF;                        // :927
       }
     }
   }

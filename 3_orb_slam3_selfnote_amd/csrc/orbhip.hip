@@ -1518,19 +1518,22 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
   return 0;
 }
 
-int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF) {
-  if (!m || !kf || !f || !matchF || kf->n < 0 || f->n < 0) return ORBX_E_ARG;
-  for (int i = 0; i < f->n; i++) matchF[i] = -1;                  // :277
+// Shared by the two SearchByBoW overloads.  kf_kf: second operand is a keyframe (candidates need a good map point, strict
+// threshold, result indexed by the first keyframe's keypoints: out[kf->n]); otherwise out[f->n] is indexed by frame keypoint.
+static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, bool kf_kf, int32_t *out) {
+  if (!m || !kf || !f || !out || kf->n < 0 || f->n < 0) return ORBX_E_ARG;
+  const int nout = kf_kf ? kf->n : f->n;
+  for (int i = 0; i < nout; i++) out[i] = -1;                     // :277 / :852
   if (kf->n == 0 || f->n == 0 || kf->n_nodes <= 0 || f->n_nodes <= 0) return 0;
   if (!kf->descriptors || !f->descriptors || !kf->has_mappoint || !kf->node_id || !f->node_id || !kf->node_start || !f->node_start ||
-      !kf->node_idx || !f->node_idx || !kf->keys_un || !f->keys_un) return ORBX_E_ARG;
+      !kf->node_idx || !f->node_idx || !kf->keys_un || !f->keys_un || (kf_kf && !f->has_mappoint)) return ORBX_E_ARG;
   // merge-walk of the two feature vectors (:292-296, :440-447): one work item per shared node
   std::vector<BowItem> items;
   int a = 0, b = 0;
   while (a < kf->n_nodes && b < f->n_nodes) {
     if (kf->node_id[a] == f->node_id[b]) {
       const int lk = kf->node_start[a + 1] - kf->node_start[a], lf = f->node_start[b + 1] - f->node_start[b];
-      if (lf > 2048) { m->err = "SearchByBoW: more than 2048 frame keypoints in one vocabulary node"; return ORBX_E_ARG; }
+      if (lf > 2048) { m->err = "SearchByBoW: more than 2048 keypoints of the second operand in one vocabulary node"; return ORBX_E_ARG; }
       if (lk > 0 && lf > 0) items.push_back(BowItem{kf->node_start[a], lk, f->node_start[b], lf});
       a++; b++;
     } else if (kf->node_id[a] < f->node_id[b]) {
@@ -1543,51 +1546,59 @@ int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe
   MCHECK(m, hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const size_t nidxKF = (size_t)kf->node_start[kf->n_nodes], nidxF = (size_t)f->node_start[f->n_nodes];
-  DevBuf bufs[7];
-  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 7; i++) b[i].release(); } } guard{bufs};
-  const size_t sz[7] = {32 * (size_t)kf->n, 32 * (size_t)f->n, (size_t)kf->n, sizeof(int32_t) * nidxKF, sizeof(int32_t) * nidxF,
-                        sizeof(BowItem) * items.size(), sizeof(int32_t) * (size_t)f->n};
-  const void *src[7] = {kf->descriptors, f->descriptors, kf->has_mappoint, kf->node_idx, f->node_idx, items.data(), matchF};
-  for (int i = 0; i < 7; i++) {
+  DevBuf bufs[8];
+  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 8; i++) b[i].release(); } } guard{bufs};
+  const size_t sz[8] = {32 * (size_t)kf->n, 32 * (size_t)f->n, (size_t)kf->n, sizeof(int32_t) * nidxKF, sizeof(int32_t) * nidxF,
+                        sizeof(BowItem) * items.size(), sizeof(int32_t) * (size_t)nout, kf_kf ? (size_t)f->n : 0};
+  const void *src[8] = {kf->descriptors, f->descriptors, kf->has_mappoint, kf->node_idx, f->node_idx, items.data(), out, kf_kf ? f->has_mappoint : nullptr};
+  for (int i = 0; i < 8; i++) {
     MCHECK(m, bufs[i].reserve(std::max<size_t>(sz[i], 4)));
-    MCHECK(m, hipMemcpyAsync(bufs[i].p, src[i], sz[i], hipMemcpyHostToDevice, s));
+    if (sz[i]) MCHECK(m, hipMemcpyAsync(bufs[i].p, src[i], sz[i], hipMemcpyHostToDevice, s));
   }
   BowParams B;
+  memset(&B, 0, sizeof(B));
   B.descKF = (const uint32_t *)bufs[0].p; B.descF = (const uint32_t *)bufs[1].p; B.hasmpKF = (const uint8_t *)bufs[2].p;
   B.node_idxKF = (const int32_t *)bufs[3].p; B.node_idxF = (const int32_t *)bufs[4].p;
   B.items = (const BowItem *)bufs[5].p; B.nitems = (int)items.size();
-  B.nnratio = nnratio; B.matchF = (int32_t *)bufs[6].p;
+  B.nnratio = nnratio;
+  if (kf_kf) { B.match12 = (int32_t *)bufs[6].p; B.hasmpF = (const uint8_t *)bufs[7].p; B.strict = 1; }
+  else B.matchF = (int32_t *)bufs[6].p;
   hipLaunchKernelGGL(k_bow_match, dim3((B.nitems + 3) / 4), dim3(256), 0, s, B);
   MCHECK(m, hipGetLastError());
-  MCHECK(m, hipMemcpyAsync(matchF, bufs[6].p, sz[6], hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipMemcpyAsync(out, bufs[6].p, sz[6], hipMemcpyDeviceToHost, s));
   MCHECK(m, hipStreamSynchronize(s));
   int nmatches = 0;
-  for (int i = 0; i < f->n; i++) nmatches += matchF[i] >= 0 ? 1 : 0;
+  for (int i = 0; i < nout; i++) nmatches += out[i] >= 0 ? 1 : 0;
   if (!checkOri) return nmatches;
-  // rotation histogram in the reference's push order (:303, node by node, keyframe keypoints in node order), :391-404, :451-466
-  std::vector<int32_t> fOfKF((size_t)kf->n, -1);
-  for (int i = 0; i < f->n; i++) if (matchF[i] >= 0) fOfKF[matchF[i]] = i;
+  // rotation histogram (:391-404, :451-466 resp. :929-939, :960-975): bins hold the index `out` is addressed with
   std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
   const float factor = 1.0f / ORBM_HISTO_LENGTH;
-  for (const BowItem &itx : items)
-    for (int k = 0; k < itx.lenKF; k++) {
-      const int idxKF = kf->node_idx[itx.startKF + k];
-      const int idxF = fOfKF[idxKF];
-      if (idxF < 0) continue;
-      float rot = kf->keys_un[idxKF].angle - f->keys_un[idxF].angle;
-      if ((double)rot < 0.0) rot += 360.0f;
-      int bin = (int)roundf(rot * factor);
-      if (bin == ORBM_HISTO_LENGTH) bin = 0;
-      if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(idxF);
-    }
+  for (int i = 0; i < nout; i++) {
+    if (out[i] < 0) continue;
+    const int idxKF = kf_kf ? i : out[i], idxF = kf_kf ? out[i] : i;
+    float rot = kf->keys_un[idxKF].angle - f->keys_un[idxF].angle;
+    if ((double)rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+    if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(i);
+  }
   int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
   for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
   orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
   for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
     if (i == ind1 || i == ind2 || i == ind3) continue;
-    for (int idx : rotHist[i]) { matchF[idx] = -1; nmatches--; }
+    for (int idx : rotHist[i]) { out[idx] = -1; nmatches--; }
   }
   return nmatches;
+}
+
+int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF) {
+  return bow_core(m, kf, f, nnratio, checkOri, false, matchF);
+}
+
+int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float nnratio, int checkOri,
+                                 int32_t *matches12) {
+  return bow_core(m, kf1, kf2, nnratio, checkOri, true, matches12);
 }
 
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {

@@ -304,6 +304,12 @@ int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm
  * vocabulary node on the device; rotation histogram on the host.  Returns nmatches. */
 int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)    (ORBmatcher.cc:839-979)
+ * has_mappoint[i] = pMP && !pMP->isBad() on both sides; matches12[kf1->n] (out) = keypoint of kf2 whose map point
+ * keypoint i of kf1 was matched with (vpMatches12[i] = vpMapPoints2[matches12[i]]) or -1.  Returns nmatches. */
+int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float nnratio, int checkOri,
+                                 int32_t *matches12);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

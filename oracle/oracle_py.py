@@ -393,6 +393,15 @@ def search_by_bow(KF, F, nnratio=0.7, check_ori=True):
     return n, m[:F.N]
 
 
+def search_by_bow_keyframes(K1, K2, nnratio=0.8, check_ori=True):
+    """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:839-979) on two OracleKeyFrame views."""
+    L = lib()
+    L.orc_search_by_bow_kf_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    m = np.full(max(K1.N, 1), -1, dtype=np.int32)
+    n = L.orc_search_by_bow_kf_kf(C.byref(K1.k), C.byref(K2.k), C.c_float(nnratio), int(check_ori), _p(m))
+    return n, m[:K1.N]
+
+
 def search_by_projection_kf(F, valid, Xw, mpdesc, kf_angle, max_dist, min_dist, Tcw, cam_type, cam_params, log_scale_factor, th, orb_dist,
                             check_ori=True):
     """M4 on an OracleFrame (ORBmatcher.cc:2291-2413); slot/slot_obs of F are updated in place."""

@@ -1866,3 +1866,63 @@ int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, fl
   for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
   return nmatches;
 }
+
+/* N3: ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&), ORBmatcher.cc:839-979 (NLeft == -1). */
+int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, float nnratio, int checkOri, int32_t *matches12) {
+  const int HISTO_LENGTH = 30, TH_LOW = 50;
+  int nmatches = 0;
+  for (int i = 0; i < K1->N; i++) matches12[i] = -1;
+  uint8_t *vbMatched2 = (uint8_t *)calloc((size_t)K2->N + 1, 1);
+  int *rotHist[30];
+  int rotN[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(K1->N + 1)); rotN[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < K1->n_nodes && b < K2->n_nodes) {
+    if (K1->node_id[a] == K2->node_id[b]) {
+      for (int i1 = K1->node_start[a]; i1 < K1->node_start[a + 1]; i1++) {
+        const int idx1 = K1->node_idx[i1];
+        if (!K1->has_mp[idx1]) continue;
+        const uint8_t *d1 = K1->desc + 32 * (size_t)idx1;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int i2 = K2->node_start[b]; i2 < K2->node_start[b + 1]; i2++) {
+          const int idx2 = K2->node_idx[i2];
+          if (vbMatched2[idx2] || !K2->has_mp[idx2]) continue;
+          const int dist = orc_descriptor_distance(d1, K2->desc + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < TH_LOW) {
+          if ((float)bestDist1 < nnratio * (float)bestDist2) {
+            matches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = 1;
+            if (checkOri) {
+              float rot = K1->angle[idx1] - K2->angle[bestIdx2];
+              if ((double)rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin][rotN[bin]++] = idx1;
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (K1->node_id[a] < K2->node_id[b]) {
+      while (a < K1->n_nodes && K1->node_id[a] < K2->node_id[b]) a++;
+    } else {
+      while (b < K2->n_nodes && K2->node_id[b] < K1->node_id[a]) b++;
+    }
+  }
+  if (checkOri) {
+    int ind1, ind2, ind3;
+    orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < rotN[i]; j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+  free(vbMatched2);
+  return nmatches;
+}

@@ -197,6 +197,8 @@ typedef struct {
 
 /* N3 (first member): SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ORBmatcher.cc:273-469 (Nleft == -1). */
 int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF);
+/* N3: SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&), ORBmatcher.cc:839-979. */
+int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, float nnratio, int checkOri, int32_t *matches12);
 
 /* M6: SearchForTriangulation(KF1, KF2, F12, pairs, bOnlyStereo, bCoarse), ORBmatcher.cc:981-1222, both cameras
  * Pinhole and no second camera (mpCamera2 == NULL).  R?w row-major 3x3, t?w 3, Cw1 = pKF1->GetCameraCenter().

@@ -460,3 +460,27 @@ def test_edge_cases_of_the_wider_api(pkg, oracle, synth, matcher):
                                                   k0["y"][:nmp] + np.float32(offs[0][1] - offs[1][1]), np.ones(nmp, np.float32), lvl,
                                                   np.ones(nmp, np.uint8), z, z, np.ones(nmp, np.float32), lvl)
     assert (mr == -1).all() and n == int((ml >= 0).sum()) and n > 10
+
+
+@pytest.mark.parametrize("nodes,check_ori", [(128, True), (16, False)])
+def test_search_by_bow_keyframes_n3(pkg, oracle, synth, nodes, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:839-979): as the KeyFrame/Frame overload, but the
+    candidates need a good map point, the threshold is strict (< TH_LOW) and the result is indexed by the first keyframe."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3850)
+    rng = np.random.default_rng(nodes + 1)
+    sigma2 = (sf * sf).astype(np.float32)
+    mp0 = (rng.random(len(k0)) < 0.8).astype(np.uint8)
+    mp1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    fv0, fv1 = _bow(d0, nodes), _bow(d1, nodes)
+    K1 = pkg.KeyFrameView(k0, d0, fv0, sf, sigma2, has_mappoint=mp0)
+    K2 = pkg.KeyFrameView(k1, d1, fv1, sf, sigma2, has_mappoint=mp1)
+    O1 = oracle.OracleKeyFrame(k0, d0, fv0, sf, sigma2, has_mp=mp0)
+    O2 = oracle.OracleKeyFrame(k1, d1, fv1, sf, sigma2, has_mp=mp1)
+    m = pkg.ORBmatcher(0.8, check_ori)                                # LoopClosing.cc: ORBmatcher matcher(0.8,true)
+    try:
+        n_gpu, m_gpu = m.SearchByBoWKeyFrames(K1, K2)
+        n_ref, m_ref = oracle.search_by_bow_keyframes(O1, O2, 0.8, check_ori)
+        assert n_gpu == n_ref and n_ref > 80
+        assert np.array_equal(m_gpu, m_ref)
+    finally:
+        m.close()
