@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -117,6 +117,8 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection_last_frame_fisheye.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32,
                                                                i32, i32, vp, vp]
     L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp]
+    L.orbm_fuse.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp]
+    L.orbm_fuse_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -553,6 +555,40 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_search_by_bow_keyframes rc=%d" % rc)
         return rc, m[:KF1.N]
+
+    def Fuse(self, KF, scale_factors, inv_level_sigma2, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Tcw, Ow,
+             cam_type, cam_params, bf, th=3.0):
+        """Search part of Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) -- ORBmatcher.cc:1425-1658.
+        KF: FrameView of the keyframe (u_right = mvuRight).  Returns (nFused, bestIdx[nP], bestDist[nP])."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf, is2 = a(scale_factors, np.float32), a(inv_level_sigma2, np.float32)
+        valid, Xw, normal, mp_desc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mp_desc, np.uint8)
+        max_dist, min_dist, Tcw, Ow, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Tcw, np.float32), a(Ow, np.float32), a(cam_params, np.float32)
+        n = len(valid)
+        bi, bd = np.full(max(n, 1), -1, np.int32), np.full(max(n, 1), 256, np.int32)
+        fs = KF.struct()
+        rc = self.L.orbm_fuse(self.m, C.byref(fs), _p(sf), _p(is2), len(sf), C.c_float(log_scale_factor), n, _p(valid), _p(Xw), _p(normal), _p(mp_desc),
+                              _p(max_dist), _p(min_dist), _p(Tcw), _p(Ow), int(cam_type), _p(cam), C.c_float(bf), C.c_float(th), _p(bi), _p(bd))
+        self._check(rc, "orbm_fuse")
+        if rc < 0:
+            raise OrbError("orbm_fuse rc=%d" % rc)
+        return rc, bi[:n], bd[:n]
+
+    def FuseSim3(self, KF, scale_factors, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Scw, cam, th=4.0):
+        """Search part of Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) -- ORBmatcher.cc:1660-1786."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        sf = a(scale_factors, np.float32)
+        valid, Xw, normal, mp_desc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mp_desc, np.uint8)
+        max_dist, min_dist, Scw, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Scw, np.float32), a(cam, np.float32)
+        n = len(valid)
+        bi, bd = np.full(max(n, 1), -1, np.int32), np.full(max(n, 1), 256, np.int32)
+        fs = KF.struct()
+        rc = self.L.orbm_fuse_sim3(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), n, _p(valid), _p(Xw), _p(normal), _p(mp_desc),
+                                   _p(max_dist), _p(min_dist), _p(Scw), _p(cam), C.c_float(th), _p(bi), _p(bd))
+        self._check(rc, "orbm_fuse_sim3")
+        if rc < 0:
+            raise OrbError("orbm_fuse_sim3 rc=%d" % rc)
+        return rc, bi[:n], bd[:n]
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

@@ -31,6 +31,9 @@ struct MatchProblemSet {
   // couple 2 = ... when the left one's window was empty (:2126); qany[q] = window of query q non-empty (scan -> resolve);
   // serial = resolve one query at a time from a fresh list (exact when a partner write can release a claim).
   int nleft; const uint8_t *qside; const int32_t *partner; int couple; uint8_t *qany; int serial;
+  // ORBmatcher::Fuse (ORBmatcher.cc:1425-1658): per-candidate chi-square gate on the reprojection error, :1585-1608
+  // (k_match_scan mode SCAN_FUSE); u_right = mvuRight of the keyframe, qur = projected right coordinate
+  float inv_sigma2[16];
   long long *dbg;  // diagnostic builds (-DRESOLVE_STAMPS) only: per-problem cycle sums; never read by the product
 };
 
@@ -136,10 +139,13 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
   return ok;
 }
 
-// STEREO: fisheye-stereo problem (image restriction per query, window-non-empty flags); the mono instantiation carries
-// none of that in its inner loop.
-// UR: the frame has mvuRight (rectified stereo / RGB-D): the right-coordinate test is compiled in.
-template <typename KT, bool STEREO, bool UR>
+// MODE selects what is compiled into the inner loop besides the window test:
+//   SCAN_PLAIN    nothing (monocular frames)
+//   SCAN_UR       the right-coordinate test of frames with mvuRight (rectified stereo / RGB-D), ORBmatcher.cc:93-98
+//   SCAN_FISHEYE  fisheye-stereo problem: image restriction per query, window-non-empty flags
+//   SCAN_FUSE     ORBmatcher::Fuse's chi-square gate on the reprojection error, ORBmatcher.cc:1585-1608
+enum { SCAN_PLAIN = 0, SCAN_UR = 1, SCAN_FISHEYE = 2, SCAN_FUSE = 3 };
+template <typename KT, int MODE>
 __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
 #pragma unroll
   for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
   // fisheye-stereo: a query sees only the keypoints of its own image
+  constexpr bool STEREO = MODE == SCAN_FISHEYE, UR = MODE == SCAN_UR;
   const int nleft = STEREO && M.qside ? M.nleft : n;
   const bool sideR = STEREO && M.qside && q < nq && M.qside[qo + q] != 0;
   const bool wantAny = STEREO && M.qany != nullptr;
@@ -202,6 +209,13 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
         viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
         bool ok = sok && (fpass & ~viol) < 0;
         if (UR) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);        // ORBmatcher.cc:93-98, :2139-2146
+        if (MODE == SCAN_FUSE) {                                          // ORBmatcher.cc:1585-1608
+          const float ex = w.u - cm.x, ey = w.v - cm.y;
+          float e2 = ex * ex + ey * ey;
+          double lim = 5.99;
+          if (cm.ur >= 0.f) { const float er = w.ur - cm.ur; e2 = e2 + er * er; lim = 7.8; }
+          ok = ok && !((double)(e2 * M.inv_sigma2[oct & 15]) > lim);
+        }
         if (ok) {
           const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
           int dist = __popc(a.x ^ qd[0]);                                 // one accumulating v_bcnt per word

@@ -634,7 +634,7 @@ struct orbm_handle {
   DevBuf d_partner, d_qside, d_qany;
   // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
   // orbm_search_by_projection_batch_device): device pointers
-  struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; int init_th_low = -1; } ext;
+  struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; int init_th_low = -1; const float *fuse_inv_sigma2 = nullptr; } ext;
   bool profiling = false;
   hipEvent_t ev[3] = {};
   bool ev_ok = false, ms_valid = false;
@@ -820,6 +820,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
   M.serial = m->ext.serial; M.qany = m->ext.qany;
   const int init_th_low = m->ext.init_th_low;  // >= 0: SearchForInitialization's resolve instead of the claim loop
+  const bool fuse = m->ext.fuse_inv_sigma2 != nullptr;
+  if (fuse) for (int i = 0; i < 16; i++) M.inv_sigma2[i] = m->ext.fuse_inv_sigma2[i];
   m->ext = {};
   const int maxn = d_frame_n ? frame_stride : f->n;
   const int maxq = d_query_n ? query_stride : q->nq;
@@ -847,9 +849,10 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (lds > 48 * 1024)                                                                                                  \
       MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, true, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);      \
-    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, false, true>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p); \
-    else hipLaunchKernelGGL((k_match_scan<KT, false, false>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);            \
+    if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
+    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);  \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);     \
+    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                 \
     if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
@@ -865,7 +868,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
 }
 
 // host-pointer fisheye-stereo options of one search (see MatchProblemSet)
-struct StereoExt { int nleft; const int32_t *partner; const uint8_t *qside; int couple; int serial; int init_th_low = -1; };
+struct StereoExt { int nleft; const int32_t *partner; const uint8_t *qside; int couple; int serial; int init_th_low = -1; const float *fuse_inv_sigma2 = nullptr; };
 
 static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q, float nnratio, int th_dist, int use_second,
                        int32_t *slot, uint8_t *slot_obs, int32_t *match_of_query, int32_t *best_dist, const StereoExt *ext);
@@ -916,6 +919,7 @@ static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q
     m->ext.serial = ext->serial;
     m->ext.qany = ext->couple == 2 ? (uint8_t *)m->d_qany.p : nullptr;
     m->ext.init_th_low = ext->init_th_low;
+    m->ext.fuse_inv_sigma2 = ext->fuse_inv_sigma2;   // host array of 16 floats, copied into the kernel arguments at launch
   }
 #undef UP
   MCHECK(m, m->d_moq.reserve(sizeof(int32_t) * (size_t)nq));
@@ -1253,6 +1257,102 @@ int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const floa
   // bestDist <= TH_LOW*ratioHamming with an int on the left: same as bestDist <= floor(50.f*ratioHamming)
   const int th_dist = (int)floorf((float)ORBM_TH_LOW * ratioHamming);
   return orbm_search_by_projection(m, &f, &q, 0.f, th_dist, 0, slot, slot_obs, nullptr, nullptr);
+}
+
+// ---- Fuse (ORBmatcher.cc:1425-1658 and :1660-1786) ------------------------------------------------------------------------
+// The search of one map point does not depend on the others (no claim: a keypoint that already holds a map point stays a
+// candidate, :1622-1640), so the device returns (bestIdx, bestDist) per map point and the caller applies the
+// Replace / AddObservation bookkeeping on its objects in order.  Projection and gates on the host in fp32 as written.
+static int fuse_core(orbm_t *m, const orbm_frame_t *kf, const float *sf, const float *inv_sigma2, int nlevels, float logScaleFactor, int nP,
+                     const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                     const float *min_dist, const float *T /* row-major 4x4 [Rcw | tcw] */, const float *Ow, int cam_type,
+                     const float *cam, float bf, float th, bool chi2, int32_t *best_idx, int32_t *best_dist) {
+  const float tcw[3] = {T[3], T[7], T[11]};
+  std::vector<float> u(nP, 0.f), v(nP, 0.f), rad(nP, 0.f), ur(nP, 0.f);
+  std::vector<int32_t> minl(nP, -1), maxl(nP, -1);
+  std::vector<uint8_t> flags(nP, 0);
+  for (int i = 0; i < nP; i++) {
+    best_idx[i] = -1; best_dist[i] = 256;
+    if (!valid[i]) continue;
+    const float *p3Dw = Xw + 3 * i;
+    float p3Dc[3];
+    mat3_mul_add(T, p3Dw, tcw, p3Dc);                                         // :1472 / :1694
+    if (p3Dc[2] < 0.0f) continue;                                             // :1475 / :1697
+    const float invz = 1 / p3Dc[2];                                           // :1481
+    float ux, vy;
+    orbm_project(cam_type, cam, p3Dc[0], p3Dc[1], p3Dc[2], &ux, &vy);         // :1487 / :1704
+    if (!(ux >= kf->min_x && ux < kf->max_x && vy >= kf->min_y && vy < kf->max_y)) continue;  // KeyFrame::IsInImage, KeyFrame.cc:844-847
+    float PO[3];
+    double n2 = 0, pd = 0;
+    for (int k = 0; k < 3; k++) { PO[k] = p3Dw[k] - Ow[k]; n2 += (double)PO[k] * (double)PO[k]; }
+    const float dist3D = (float)sqrt(n2);                                     // cv::norm, :1502 / :1715
+    if (dist3D < 0.8f * min_dist[i] || dist3D > 1.2f * max_dist[i]) continue; // MapPoint.cc:552-563, :1505 / :1718
+    for (int k = 0; k < 3; k++) pd += (double)PO[k] * (double)normal[3 * i + k];
+    if (pd < 0.5 * (double)dist3D) continue;                                  // :1514 / :1724
+    const float ratio = max_dist[i] / dist3D;                                 // MapPoint::PredictScale, MapPoint.cc:570-585
+    int lvl = (int)ceilf(logf(ratio) / logScaleFactor);
+    lvl = lvl < 0 ? 0 : (lvl >= nlevels ? nlevels - 1 : lvl);
+    u[i] = ux; v[i] = vy; ur[i] = ux - bf * invz;                             // :1495
+    rad[i] = th * sf[lvl];                                                    // :1524 / :1731
+    minl[i] = lvl - 1; maxl[i] = lvl;                                         // :1555 / :1752
+    flags[i] = 1;                                                             // takes part, never claims
+  }
+  orbm_queries_t q;
+  q.nq = nP; q.descriptors = mpdesc; q.u = u.data(); q.v = v.data(); q.radius = rad.data();
+  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = ur.data(); q.flags = flags.data();
+  orbm_frame_t f = *kf;
+  std::vector<float> no_ur;
+  if (chi2 && !f.u_right) { no_ur.assign((size_t)std::max(kf->n, 1), -1.0f); f.u_right = no_ur.data(); }
+  if (!chi2) f.u_right = nullptr;
+  std::vector<int32_t> slot((size_t)std::max(kf->n, 1), -1);
+  std::vector<uint8_t> sobs((size_t)std::max(kf->n, 1), 0);
+  float is2[16] = {0};
+  StereoExt ext{};
+  ext.nleft = kf->n;
+  if (chi2) { for (int l = 0; l < nlevels && l < 16; l++) is2[l] = inv_sigma2[l]; ext.fuse_inv_sigma2 = is2; }
+  const int rc = search_host(m, &f, &q, 0.f, ORBM_TH_LOW, 0, slot.data(), sobs.data(), best_idx, best_dist, &ext);
+  if (rc < 0) return rc;
+  int nFused = 0;
+  for (int i = 0; i < nP; i++) nFused += best_idx[i] >= 0 ? 1 : 0;           // bestDist <= TH_LOW, :1622 / :1767
+  return nFused;
+}
+
+int orbm_fuse(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, const float *inv_level_sigma2, int nlevels,
+              float log_scale_factor, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+              const float *max_dist, const float *min_dist, const float *Tcw, const float *Ow, int cam_type, const float *cam_params,
+              float bf, float th, int32_t *best_idx, int32_t *best_dist) {
+  if (!m || !kf || !scale_factors || !inv_level_sigma2 || nlevels < 1 || nlevels > 16 || nP < 0 || !Tcw || !Ow || !cam_params || !best_idx || !best_dist) return ORBX_E_ARG;
+  if (nP > 0 && (!valid || !Xw || !normal || !mpdesc || !max_dist || !min_dist)) return ORBX_E_ARG;
+  if (nP == 0) return 0;
+  return fuse_core(m, kf, scale_factors, inv_level_sigma2, nlevels, log_scale_factor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, Tcw, Ow,
+                   cam_type, cam_params, bf, th, true, best_idx, best_dist);
+}
+
+int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
+                   const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                   const float *min_dist, const float *Scw, const float *cam, float th, int32_t *best_idx, int32_t *best_dist) {
+  if (!m || !kf || !scale_factors || nlevels < 1 || nP < 0 || !Scw || !cam || !best_idx || !best_dist) return ORBX_E_ARG;
+  if (nP > 0 && (!valid || !Xw || !normal || !mpdesc || !max_dist || !min_dist)) return ORBX_E_ARG;
+  if (nP == 0) return 0;
+  // Decompose Scw, :1668-1673 (as in orbm_search_by_projection_sim3)
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)sqrt(dot);
+  const double inv = 1. / (double)scw;
+  float T[16] = {0};
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)((double)Scw[4 * i + j] * inv);
+    T[4 * i + 3] = (float)((double)Scw[4 * i + 3] * inv);
+  }
+  const float tcw[3] = {T[3], T[7], T[11]};
+  float Ow[3];
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)T[4 * k + i] * (double)tcw[k];
+    Ow[i] = (float)(-acc);
+  }
+  return fuse_core(m, kf, scale_factors, nullptr, nlevels, log_scale_factor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, T, Ow, 0, cam,
+                   0.f, th, false, best_idx, best_dist);
 }
 
 // ---- SearchForTriangulation (ORBmatcher.cc:981-1222), Pinhole / Pinhole, no second camera --------------------------------

@@ -253,6 +253,26 @@ int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const floa
                                    const float *min_dist, const float *Scw, const float *cam, int th,
                                    float ratioHamming, int32_t *slot, uint8_t *slot_obs);
 
+/* int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th, const bool bRight = false)
+ *                                                                                             (ORBmatcher.cc:1425-1658)
+ * kf = the keyframe's mvKeysUn / mDescriptors / mvuRight (NULL = all -1) / image bounds; i in [0, nP): valid[i] =
+ * pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF); Xw = GetWorldPos(), normal = GetNormal(), mpdesc = GetDescriptor(),
+ * max_dist / min_dist = mfMaxDistance / mfMinDistance (the 1.2 / 0.8 invariance factors are applied inside);
+ * Tcw = row-major 4x4 [GetRotation() | GetTranslation()], Ow = GetCameraCenter(); cam as in orbm_project; bf = pKF->mbf.
+ * The search of one map point does not depend on the others, so the function returns the per-point result -
+ * best_idx[i] = keypoint (bestDist <= TH_LOW) or -1, best_dist[i] - and the caller applies :1622-1640 (Replace /
+ * AddObservation / AddMapPoint) on its objects in index order.  Returns nFused = #{i : best_idx[i] >= 0}. */
+int orbm_fuse(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, const float *inv_level_sigma2, int nlevels,
+              float log_scale_factor, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+              const float *max_dist, const float *min_dist, const float *Tcw, const float *Ow, int cam_type, const float *cam_params,
+              float bf, float th, int32_t *best_idx, int32_t *best_dist);
+/* int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th,
+ *                      vector<MapPoint*> &vpReplacePoint)                                      (ORBmatcher.cc:1660-1786)
+ * valid[i] = !pMP->isBad() && !spAlreadyFound.count(pMP); Scw row-major 4x4 (Sim3); cam = {fx, fy, cx, cy}. */
+int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
+                   const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                   const float *min_dist, const float *Scw, const float *cam, float th, int32_t *best_idx, int32_t *best_dist);
+
 /* The slice of KeyFrame that SearchForTriangulation reads (host pointers).  feature vector = DBoW2::FeatureVector
  * (std::map<NodeId, std::vector<unsigned>>, FeatureVector.h:24-25) flattened in key order: node_id[k] ascending,
  * members of node k = node_idx[node_start[k] .. node_start[k+1]). */

@@ -428,6 +428,34 @@ def search_by_projection_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, 
                                            _p(Scw), _p(cam), C.c_float(log_scale_factor), int(th), C.c_float(ratio_hamming), _p(F.slot), _p(F.slot_obs))
 
 
+def fuse(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Tcw, Ow, cam_type, cam, bf, inv_sigma2, log_scale_factor, th):
+    """Search part of Fuse(KeyFrame*, vpMapPoints, th) (ORBmatcher.cc:1425-1658) on an OracleFrame of the keyframe."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    n = len(valid)
+    bi, bd = np.full(n, -1, np.int32), np.full(n, 256, np.int32)
+    L = lib()
+    L.orc_fuse.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    args = [a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mpdesc, np.uint8), a(max_dist, np.float32), a(min_dist, np.float32),
+            a(Tcw, np.float32), a(Ow, np.float32)]
+    cam, inv_sigma2 = a(cam, np.float32), a(inv_sigma2, np.float32)
+    nf = L.orc_fuse(C.byref(F.f), n, *[_p(x) for x in args], int(cam_type), _p(cam), C.c_float(bf), _p(inv_sigma2), C.c_float(log_scale_factor),
+                    C.c_float(th), _p(bi), _p(bd))
+    return nf, bi, bd
+
+
+def fuse_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th):
+    """Search part of Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:1660-1786)."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    n = len(valid)
+    bi, bd = np.full(n, -1, np.int32), np.full(n, 256, np.int32)
+    L = lib()
+    L.orc_fuse_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    args = [a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mpdesc, np.uint8), a(max_dist, np.float32), a(min_dist, np.float32),
+            a(Scw, np.float32), a(cam, np.float32)]
+    nf = L.orc_fuse_sim3(C.byref(F.f), n, *[_p(x) for x in args], C.c_float(log_scale_factor), C.c_float(th), _p(bi), _p(bd))
+    return nf, bi, bd
+
+
 def undistort_points(xy, K, D):
     xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
     K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)

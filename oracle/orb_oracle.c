@@ -1926,3 +1926,105 @@ int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, floa
   free(vbMatched2);
   return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N3: ORBmatcher::Fuse.  chi2 != 0: Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight=false),  */
+/* ORBmatcher.cc:1425-1658 (T = [Rcw | tcw] row-major 3x3 + 3, Ow, camera, bf, invLevelSigma2).     */
+/* chi2 == 0: Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint), :1660-1786, with T / Ow   */
+/* from the Sim3 decomposition (orc_fuse_sim3).  Only the per-point search is restated: bestIdx[i]  */
+/* (bestDist <= TH_LOW) or -1, bestDist[i]; the Replace / AddObservation bookkeeping acts on objects */
+/* that do not feed back into the search.                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static int fuse_impl(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                     const float *maxDist, const float *minDist, const float *Rcw, const float *tcw, const float *Ow, int camType,
+                     const float *cam, float bf, const float *invLevelSigma2, float logScaleFactor, float th, int chi2,
+                     int32_t *bestIdxOut, int32_t *bestDistOut) {
+  int nFused = 0;
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kf->N > 0 ? kf->N : 1));
+  for (int i = 0; i < nP; i++) {
+    bestIdxOut[i] = -1; bestDistOut[i] = 256;
+    if (!valid[i]) continue;
+    const float *p3Dw = Xw + 3 * i;
+    float p3Dc[3];
+    mat3_mul_add(Rcw, 3, p3Dw, tcw, p3Dc);
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = 1 / p3Dc[2];
+    float uvx, uvy;
+    orc_project(camType, cam, p3Dc[0], p3Dc[1], p3Dc[2], &uvx, &uvy);
+    if (!(uvx >= kf->mnMinX && uvx < kf->mnMaxX && uvy >= kf->mnMinY && uvy < kf->mnMaxY)) continue;
+    const float ur = uvx - bf * invz;
+    const float maxDistance = 1.2f * maxDist[i], minDistance = 0.8f * minDist[i];
+    float PO[3];
+    double n2 = 0, pd = 0;
+    for (int k = 0; k < 3; k++) { PO[k] = p3Dw[k] - Ow[k]; n2 += (double)PO[k] * (double)PO[k]; }
+    const float dist3D = (float)sqrt(n2);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    for (int k = 0; k < 3; k++) pd += (double)PO[k] * (double)normal[3 * i + k];
+    if (pd < 0.5 * (double)dist3D) continue;
+    const float ratio = maxDist[i] / dist3D;
+    int nPredictedLevel = (int)ceilf(logf(ratio) / logScaleFactor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= kf->nlevels) nPredictedLevel = kf->nlevels - 1;
+    const float radius = th * kf->mvScaleFactors[nPredictedLevel];
+    const int nv = orc_get_features_in_area(kf, uvx, uvy, radius, -1, -1, vIndices);
+    if (nv == 0) continue;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < nv; k++) {
+      const int idx = vIndices[k];
+      const int kpLevel = kf->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (chi2) {
+        const float kpx = kf->kx[idx], kpy = kf->ky[idx];
+        const float kur = kf->uRight ? kf->uRight[idx] : -1.0f;
+        if (kur >= 0) {
+          const float ex = uvx - kpx, ey = uvy - kpy, er = ur - kur;
+          const float e2 = ex * ex + ey * ey + er * er;
+          if ((double)(e2 * invLevelSigma2[kpLevel]) > 7.8) continue;
+        } else {
+          const float ex = uvx - kpx, ey = uvy - kpy;
+          const float e2 = ex * ex + ey * ey;
+          if ((double)(e2 * invLevelSigma2[kpLevel]) > 5.99) continue;
+        }
+      }
+      const int dist = orc_descriptor_distance(dMP, kf->desc + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= 50 /* TH_LOW */) {
+      bestIdxOut[i] = bestIdx;
+      bestDistOut[i] = bestDist;
+      nFused++;
+    }
+  }
+  free(vIndices);
+  return nFused;
+}
+
+int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+             const float *maxDist, const float *minDist, const float *Tcw /* row-major 4x4 */, const float *Ow, int camType,
+             const float *cam, float bf, const float *invLevelSigma2, float logScaleFactor, float th, int32_t *bestIdx, int32_t *bestDist) {
+  float Rcw[9], tcw[3];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rcw[3 * i + j] = Tcw[4 * i + j]; tcw[i] = Tcw[4 * i + 3]; }
+  return fuse_impl(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Rcw, tcw, Ow, camType, cam, bf, invLevelSigma2, logScaleFactor, th, 1,
+                   bestIdx, bestDist);
+}
+
+int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                  const float *maxDist, const float *minDist, const float *Scw, const float *cam, float logScaleFactor, float th,
+                  int32_t *bestIdx, int32_t *bestDist) {
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)sqrt(dot);
+  const double inv = 1. / (double)scw;
+  float Rcw[9], tcw[3], Ow[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) Rcw[i * 3 + j] = (float)((double)Scw[i * 4 + j] * inv);
+    tcw[i] = (float)((double)Scw[i * 4 + 3] * inv);
+  }
+  for (int i = 0; i < 3; i++) {
+    double sacc = 0;
+    for (int k = 0; k < 3; k++) sacc += (double)Rcw[k * 3 + i] * (double)tcw[k];
+    Ow[i] = (float)(sacc * -1.0);
+  }
+  return fuse_impl(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Rcw, tcw, Ow, 0, cam, 0.f, NULL, logScaleFactor, th, 0, bestIdx, bestDist);
+}

@@ -197,6 +197,13 @@ typedef struct {
 
 /* N3 (first member): SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ORBmatcher.cc:273-469 (Nleft == -1). */
 int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF);
+/* N3: the search part of the two ORBmatcher::Fuse overloads, ORBmatcher.cc:1425-1658 and :1660-1786. */
+int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+             const float *maxDist, const float *minDist, const float *Tcw, const float *Ow, int camType, const float *cam, float bf,
+             const float *invLevelSigma2, float logScaleFactor, float th, int32_t *bestIdx, int32_t *bestDist);
+int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                  const float *maxDist, const float *minDist, const float *Scw, const float *cam, float logScaleFactor, float th,
+                  int32_t *bestIdx, int32_t *bestDist);
 /* N3: SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&), ORBmatcher.cc:839-979. */
 int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, float nnratio, int checkOri, int32_t *matches12);
 

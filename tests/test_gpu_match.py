@@ -484,3 +484,51 @@ def test_search_by_bow_keyframes_n3(pkg, oracle, synth, nodes, check_ori):
         assert np.array_equal(m_gpu, m_ref)
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("cam,stereo", [(0, False), (0, True), (1, False)])
+def test_fuse_n3(pkg, oracle, synth, matcher, cam, stereo):
+    """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) search part (ORBmatcher.cc:1425-1620): projection, depth-range and viewing
+    gates, PredictScale, [lvl-1, lvl] window, chi-square gate on the reprojection error (5.99 mono / 7.8 with mvuRight)."""
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, u_right = _m3_scene(pkg, oracle, synth, 3950 + cam, cam, stereo)
+    rng = np.random.default_rng(41)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    Ow = (-Tcw[:3, :3].T.astype(np.float64) @ Tcw[:3, 3].astype(np.float64)).astype(np.float32)
+    dist_last = np.sqrt(((Xw - Ow) .astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+    max_dist = (dist_last * sf[k0["octave"]]).astype(np.float32)
+    min_dist = (max_dist / sf[-1]).astype(np.float32)
+    normal = ((Xw - Ow) / np.maximum(np.linalg.norm(Xw - Ow, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    normal[rng.random(len(k0)) < 0.1] *= np.float32(-1)
+    inv_sigma2 = (1.0 / (sf * sf)).astype(np.float32)
+    log_sf = float(np.log(np.float32(1.2)))
+    KF = pkg.FrameView(k1, d1, bounds, u_right=u_right)
+    OKF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf, u_right=u_right)
+    total = 0
+    for th in (3.0, 8.0):
+        n_gpu, bi_gpu, bd_gpu = matcher.Fuse(KF, sf, inv_sigma2, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Tcw, Ow, cam, params, 47.9, th)
+        n_ref, bi_ref, bd_ref = oracle.fuse(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Tcw, Ow, cam, params, 47.9, inv_sigma2, log_sf, th)
+        assert n_gpu == n_ref
+        assert np.array_equal(bi_gpu, bi_ref) and np.array_equal(bd_gpu, bd_ref)
+        total += n_ref
+    assert total > (100 if (cam == 0 and not stereo) else 20 if cam == 0 else 0)   # the 3-term chi-square gate is tight in the stereo scene
+
+
+def test_fuse_sim3_n3(pkg, oracle, synth, matcher):
+    """ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) search part (ORBmatcher.cc:1660-1766)."""
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3960, 0, False)
+    rng = np.random.default_rng(43)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    Scw = Tcw.copy()
+    Scw[:3, :] *= np.float32(0.83)
+    dist_last = np.sqrt((Xw.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+    max_dist = (dist_last * sf[k0["octave"]]).astype(np.float32)
+    min_dist = (max_dist / sf[-1]).astype(np.float32)
+    normal = (Xw / np.maximum(np.linalg.norm(Xw, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    normal[rng.random(len(k0)) < 0.1] *= np.float32(-1)
+    log_sf = float(np.log(np.float32(1.2)))
+    KF = pkg.FrameView(k1, d1, bounds)
+    OKF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
+    n_gpu, bi_gpu, bd_gpu = matcher.FuseSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 4.0)
+    n_ref, bi_ref, bd_ref = oracle.fuse_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 4.0)
+    assert n_gpu == n_ref and n_ref > 100
+    assert np.array_equal(bi_gpu, bi_ref) and np.array_equal(bd_gpu, bd_ref)
