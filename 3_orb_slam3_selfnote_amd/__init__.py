@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -119,6 +119,7 @@ def load(build_if_needed=True):
     L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp]
     L.orbm_fuse.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp]
     L.orbm_fuse_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
+    L.orbm_search_by_sim3.argtypes = [vp] + [vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp] * 2 + [f32, vp, vp, vp, f32, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -589,6 +590,29 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_fuse_sim3 rc=%d" % rc)
         return rc, bi[:n], bd[:n]
+
+    def SearchBySim3(self, KF1, side1, KF2, side2, s12, R12, t12, cam1, th):
+        """SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12, s12, R12, t12, th) -- ORBmatcher.cc:1788-2012.
+        KF1, KF2: FrameView of the keyframes; side_k = dict(sf, log_sf, valid, Xw, desc, max_dist, min_dist, Rw, tw).
+        Returns (nFound, matches12[KF1.N])."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        keep = []
+
+        def pack(KF, S):
+            sf = a(S["sf"], np.float32)
+            arrs = [a(S["valid"], np.uint8), a(S["Xw"], np.float32), a(S["desc"], np.uint8), a(S["max_dist"], np.float32), a(S["min_dist"], np.float32),
+                    a(S["Rw"], np.float32), a(S["tw"], np.float32)]
+            fs = KF.struct()
+            keep.extend([sf, fs] + arrs)
+            return [C.byref(fs), _p(sf), len(sf), C.c_float(S["log_sf"])] + [_p(x) for x in arrs]
+
+        R12, t12, cam1 = a(R12, np.float32), a(t12, np.float32), a(cam1, np.float32)
+        m12 = np.full(max(KF1.N, 1), -1, np.int32)
+        rc = self.L.orbm_search_by_sim3(self.m, *pack(KF1, side1), *pack(KF2, side2), C.c_float(s12), _p(R12), _p(t12), _p(cam1), C.c_float(th), _p(m12))
+        self._check(rc, "orbm_search_by_sim3")
+        if rc < 0:
+            raise OrbError("orbm_search_by_sim3 rc=%d" % rc)
+        return rc, m12[:KF1.N]
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

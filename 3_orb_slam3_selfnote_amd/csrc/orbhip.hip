@@ -1355,6 +1355,95 @@ int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors
                    0.f, th, false, best_idx, best_dist);
 }
 
+// ---- SearchBySim3 (ORBmatcher.cc:1788-2012) ------------------------------------------------------------------------------
+// Two independent no-claim searches (map points of KF1 in KF2 and back) and a mutual-consistency pass.  cv::Mat algebra per
+// SURVEY.md A.8 [OPENCV-UNVERIFIED]: scalar * Mat scales in double; a product with a transposed or scaled operand
+// accumulates in double; plain 3x3 * 3x1 + 3x1 takes the small-matrix float path (mat3_mul_add).
+namespace {
+struct Sim3Side {  // queries of one direction
+  std::vector<float> u, v, rad;
+  std::vector<int32_t> minl, maxl, best;
+  std::vector<uint8_t> flags;
+};
+// Points of keyframe A (world Xw, pose RAw/tAw) into keyframe B through p_B = sRBA * p_A + tBA.
+void sim3_project(const orbm_frame_t *kfB, const float *sfB, int nlevelsB, float logSfB, int nA, const uint8_t *valid, const float *Xw,
+                  const float *max_dist, const float *min_dist, const float *RAw, const float *tAw, const float *sRBA, const float *tBA,
+                  const float *cam, float th, Sim3Side &S) {
+  S.u.assign(nA, 0.f); S.v.assign(nA, 0.f); S.rad.assign(nA, 0.f);
+  S.minl.assign(nA, -1); S.maxl.assign(nA, -1); S.best.assign(nA, -1); S.flags.assign(nA, 0);
+  float TA[16] = {0}, TB[16] = {0};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { TA[4 * i + j] = RAw[3 * i + j]; TB[4 * i + j] = sRBA[3 * i + j]; }
+  for (int i = 0; i < nA; i++) {
+    if (!valid[i]) continue;                                                   // :1828-1832
+    float pA[3], pB[3];
+    mat3_mul_add(TA, Xw + 3 * i, tAw, pA);                                     // :1835
+    mat3_mul_add(TB, pA, tBA, pB);                                             // :1836
+    if ((double)pB[2] < 0.0) continue;                                         // :1839
+    const float invz = (float)(1.0 / (double)pB[2]);                           // :1842
+    const float x = pB[0] * invz, y = pB[1] * invz;
+    const float u = cam[0] * x + cam[2], v = cam[1] * y + cam[3];              // :1846-1847, pKF1's intrinsics in both directions
+    if (!(u >= kfB->min_x && u < kfB->max_x && v >= kfB->min_y && v < kfB->max_y)) continue;  // KeyFrame::IsInImage
+    double n2 = 0;
+    for (int k = 0; k < 3; k++) n2 += (double)pB[k] * (double)pB[k];
+    const float dist3D = (float)sqrt(n2);                                      // cv::norm, :1855
+    if (dist3D < 0.8f * min_dist[i] || dist3D > 1.2f * max_dist[i]) continue;  // :1858
+    const float ratio = max_dist[i] / dist3D;                                  // MapPoint::PredictScale, MapPoint.cc:570-585
+    int lvl = (int)ceilf(logf(ratio) / logSfB);
+    lvl = lvl < 0 ? 0 : (lvl >= nlevelsB ? nlevelsB - 1 : lvl);
+    S.u[i] = u; S.v[i] = v; S.rad[i] = th * sfB[lvl];                          // :1865
+    S.minl[i] = lvl - 1; S.maxl[i] = lvl;                                      // :1884
+    S.flags[i] = 1;
+  }
+}
+}  // namespace
+
+int orbm_search_by_sim3(orbm_t *m, const orbm_frame_t *kf1, const float *sf1, int nlevels1, float log_sf1, const uint8_t *valid1,
+                        const float *Xw1, const uint8_t *mpdesc1, const float *max_dist1, const float *min_dist1, const float *R1w,
+                        const float *t1w, const orbm_frame_t *kf2, const float *sf2, int nlevels2, float log_sf2, const uint8_t *valid2,
+                        const float *Xw2, const uint8_t *mpdesc2, const float *max_dist2, const float *min_dist2, const float *R2w,
+                        const float *t2w, float s12, const float *R12, const float *t12, const float *cam1, float th, int32_t *matches12) {
+  if (!m || !kf1 || !kf2 || !sf1 || !sf2 || nlevels1 < 1 || nlevels2 < 1 || !R1w || !t1w || !R2w || !t2w || !R12 || !t12 || !cam1 || !matches12)
+    return ORBX_E_ARG;
+  const int N1 = kf1->n, N2 = kf2->n;
+  if (N1 < 0 || N2 < 0) return ORBX_E_ARG;
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  if (N1 == 0 || N2 == 0) return 0;
+  if (!valid1 || !Xw1 || !mpdesc1 || !max_dist1 || !min_dist1 || !valid2 || !Xw2 || !mpdesc2 || !max_dist2 || !min_dist2) return ORBX_E_ARG;
+  float sR12[9], sR21[9], t21[3];
+  const double a21 = 1.0 / (double)s12;                                        // :1806
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      sR12[3 * i + j] = (float)((double)R12[3 * i + j] * (double)s12);         // :1805
+      sR21[3 * i + j] = (float)((double)R12[3 * j + i] * a21);
+    }
+  for (int i = 0; i < 3; i++) {                                                // t21 = -sR21*t12, :1807
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)sR21[3 * i + k] * (double)t12[k];
+    t21[i] = (float)(acc * -1.0);
+  }
+  Sim3Side A, B;
+  sim3_project(kf2, sf2, nlevels2, log_sf2, N1, valid1, Xw1, max_dist1, min_dist1, R1w, t1w, sR21, t21, cam1, th, A);
+  sim3_project(kf1, sf1, nlevels1, log_sf1, N2, valid2, Xw2, max_dist2, min_dist2, R2w, t2w, sR12, t12, cam1, th, B);
+  struct Run { const orbm_frame_t *kf; Sim3Side *S; const uint8_t *desc; int nq; } runs[2] = {{kf2, &A, mpdesc1, N1}, {kf1, &B, mpdesc2, N2}};
+  for (const Run &r : runs) {
+    orbm_queries_t q;
+    q.nq = r.nq; q.descriptors = r.desc; q.u = r.S->u.data(); q.v = r.S->v.data(); q.radius = r.S->rad.data();
+    q.min_level = r.S->minl.data(); q.max_level = r.S->maxl.data(); q.u_r = nullptr; q.flags = r.S->flags.data();
+    orbm_frame_t f = *r.kf;
+    f.u_right = nullptr;
+    std::vector<int32_t> slot((size_t)r.kf->n, -1);
+    std::vector<uint8_t> sobs((size_t)r.kf->n, 0);
+    const int rc = search_host(m, &f, &q, 0.f, ORBM_TH_HIGH, 0, slot.data(), sobs.data(), r.S->best.data(), nullptr, nullptr);  // :1895, :1967
+    if (rc < 0) return rc;
+  }
+  int nFound = 0;                                                              // :1973-1987
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int idx2 = A.best[i1];
+    if (idx2 >= 0 && B.best[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+  }
+  return nFound;
+}
+
 // ---- SearchForTriangulation (ORBmatcher.cc:981-1222), Pinhole / Pinhole, no second camera --------------------------------
 namespace {
 // cv::Mat algebra of ORBmatcher.cc:988-1010 and Pinhole.cpp:143-148 restated ([OPENCV-UNVERIFIED]):

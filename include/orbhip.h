@@ -273,6 +273,19 @@ int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors
                    const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
                    const float *min_dist, const float *Scw, const float *cam, float th, int32_t *best_idx, int32_t *best_dist);
 
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12,
+ *                              const cv::Mat &R12, const cv::Mat &t12, const float th)           (ORBmatcher.cc:1788-2012)
+ * Per keyframe k: kf_k = mvKeysUn / mDescriptors / image bounds, sf_k = mvScaleFactors, log_sf_k = mfLogScaleFactor,
+ * valid_k[i] = pMP && !pMP->isBad() && !vbAlreadyMatched_k[i] (:1813-1826), Xw / mpdesc / max_dist / min_dist of the map point
+ * of keypoint i, R_kw / t_kw = GetRotation() / GetTranslation() (row-major 3x3 / 3).  cam1 = {fx, fy, cx, cy} of pKF1 (used
+ * for both projections, as in the reference).  matches12[kf1->n] (out) = keypoint of kf2 or -1 for the NEW mutual matches
+ * (vpMatches12[i1] = vpMapPoints2[matches12[i1]]).  Returns nFound. */
+int orbm_search_by_sim3(orbm_t *m, const orbm_frame_t *kf1, const float *sf1, int nlevels1, float log_sf1, const uint8_t *valid1,
+                        const float *Xw1, const uint8_t *mpdesc1, const float *max_dist1, const float *min_dist1, const float *R1w,
+                        const float *t1w, const orbm_frame_t *kf2, const float *sf2, int nlevels2, float log_sf2, const uint8_t *valid2,
+                        const float *Xw2, const uint8_t *mpdesc2, const float *max_dist2, const float *min_dist2, const float *R2w,
+                        const float *t2w, float s12, const float *R12, const float *t12, const float *cam1, float th, int32_t *matches12);
+
 /* The slice of KeyFrame that SearchForTriangulation reads (host pointers).  feature vector = DBoW2::FeatureVector
  * (std::map<NodeId, std::vector<unsigned>>, FeatureVector.h:24-25) flattened in key order: node_id[k] ascending,
  * members of node k = node_idx[node_start[k] .. node_start[k+1]). */

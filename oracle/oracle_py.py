@@ -456,6 +456,22 @@ def fuse_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_sc
     return nf, bi, bd
 
 
+def search_by_sim3(F1, log_sf1, valid1, Xw1, desc1, maxd1, mind1, R1w, t1w, F2, log_sf2, valid2, Xw2, desc2, maxd2, mind2, R2w, t2w, s12, R12, t12,
+                   cam1, th):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1788-2012) on two OracleFrame views of the keyframes."""
+    a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+    L = lib()
+    L.orc_search_by_sim3.argtypes = ([C.c_void_p, C.c_float] + [C.c_void_p] * 7 + [C.c_void_p, C.c_float] + [C.c_void_p] * 7 +
+                                     [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p])
+    m12 = np.full(max(F1.N, 1), -1, np.int32)
+    s1 = [a(valid1, np.uint8), a(Xw1, np.float32), a(desc1, np.uint8), a(maxd1, np.float32), a(mind1, np.float32), a(R1w, np.float32), a(t1w, np.float32)]
+    s2 = [a(valid2, np.uint8), a(Xw2, np.float32), a(desc2, np.uint8), a(maxd2, np.float32), a(mind2, np.float32), a(R2w, np.float32), a(t2w, np.float32)]
+    R12, t12, cam1 = a(R12, np.float32), a(t12, np.float32), a(cam1, np.float32)
+    n = L.orc_search_by_sim3(C.byref(F1.f), C.c_float(log_sf1), *[_p(x) for x in s1], C.byref(F2.f), C.c_float(log_sf2), *[_p(x) for x in s2],
+                             C.c_float(s12), _p(R12), _p(t12), _p(cam1), C.c_float(th), _p(m12))
+    return n, m12[:F1.N]
+
+
 def undistort_points(xy, K, D):
     xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
     K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)

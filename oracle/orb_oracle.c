@@ -2028,3 +2028,82 @@ int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, 
   }
   return fuse_impl(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Rcw, tcw, Ow, 0, cam, 0.f, NULL, logScaleFactor, th, 0, bestIdx, bestDist);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N3: ORBmatcher::SearchBySim3, ORBmatcher.cc:1788-2012.  cv::Mat algebra per SURVEY.md A.8      */
+/* [OPENCV-UNVERIFIED]: scalar * Mat in double, products with a transposed / scaled operand       */
+/* accumulate in double, plain 3x3*3x1+3x1 on the small-matrix float path.                        */
+/* ------------------------------------------------------------------------------------------ */
+static void sim3_dir(orc_frame *kfB, float logSfB, int nA, const uint8_t *valid, const float *Xw, const uint8_t *mpdesc,
+                     const float *maxDist, const float *minDist, const float *RAw, const float *tAw, const float *sRBA,
+                     const float *tBA, const float *cam, float th, int32_t *vnMatch) {
+  int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kfB->N > 0 ? kfB->N : 1));
+  for (int i = 0; i < nA; i++) {
+    vnMatch[i] = -1;
+    if (!valid[i]) continue;
+    float pA[3], pB[3];
+    mat3_mul_add(RAw, 3, Xw + 3 * i, tAw, pA);
+    mat3_mul_add(sRBA, 3, pA, tBA, pB);
+    if ((double)pB[2] < 0.0) continue;
+    const float invz = (float)(1.0 / (double)pB[2]);
+    const float x = pB[0] * invz, y = pB[1] * invz;
+    const float u = cam[0] * x + cam[2], v = cam[1] * y + cam[3];
+    if (!(u >= kfB->mnMinX && u < kfB->mnMaxX && v >= kfB->mnMinY && v < kfB->mnMaxY)) continue;
+    const float maxDistance = 1.2f * maxDist[i], minDistance = 0.8f * minDist[i];
+    double n2 = 0;
+    for (int k = 0; k < 3; k++) n2 += (double)pB[k] * (double)pB[k];
+    const float dist3D = (float)sqrt(n2);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float ratio = maxDist[i] / dist3D;
+    int nPredictedLevel = (int)ceilf(logf(ratio) / logSfB);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= kfB->nlevels) nPredictedLevel = kfB->nlevels - 1;
+    const float radius = th * kfB->mvScaleFactors[nPredictedLevel];
+    const int nv = orc_get_features_in_area(kfB, u, v, radius, -1, -1, vIndices);
+    if (nv == 0) continue;
+    const uint8_t *dMP = mpdesc + 32 * (size_t)i;
+    int bestDist = 2147483647, bestIdx = -1;
+    for (int k = 0; k < nv; k++) {
+      const int idx = vIndices[k];
+      if (kfB->octave[idx] < nPredictedLevel - 1 || kfB->octave[idx] > nPredictedLevel) continue;
+      const int dist = orc_descriptor_distance(dMP, kfB->desc + 32 * (size_t)idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= 100 /* TH_HIGH */) vnMatch[i] = bestIdx;
+  }
+  free(vIndices);
+}
+
+int orc_search_by_sim3(orc_frame *kf1, float logSf1, const uint8_t *valid1, const float *Xw1, const uint8_t *mpdesc1,
+                       const float *maxDist1, const float *minDist1, const float *R1w, const float *t1w, orc_frame *kf2, float logSf2,
+                       const uint8_t *valid2, const float *Xw2, const uint8_t *mpdesc2, const float *maxDist2, const float *minDist2,
+                       const float *R2w, const float *t2w, float s12, const float *R12, const float *t12, const float *cam1, float th,
+                       int32_t *matches12) {
+  float sR12[9], sR21[9], t21[3];
+  const double a21 = 1.0 / (double)s12;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      sR12[3 * i + j] = (float)((double)R12[3 * i + j] * (double)s12);
+      sR21[3 * i + j] = (float)((double)R12[3 * j + i] * a21);
+    }
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)sR21[3 * i + k] * (double)t12[k];
+    t21[i] = (float)(acc * -1.0);
+  }
+  const int N1 = kf1->N, N2 = kf2->N;
+  int32_t *vnMatch1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N1 + 1)), *vnMatch2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N2 + 1));
+  sim3_dir(kf2, logSf2, N1, valid1, Xw1, mpdesc1, maxDist1, minDist1, R1w, t1w, sR21, t21, cam1, th, vnMatch1);
+  sim3_dir(kf1, logSf1, N2, valid2, Xw2, mpdesc2, maxDist2, minDist2, R2w, t2w, sR12, t12, cam1, th, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    matches12[i1] = -1;
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      const int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+    }
+  }
+  free(vnMatch1); free(vnMatch2);
+  return nFound;
+}

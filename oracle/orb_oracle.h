@@ -204,6 +204,12 @@ int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const
 int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
                   const float *maxDist, const float *minDist, const float *Scw, const float *cam, float logScaleFactor, float th,
                   int32_t *bestIdx, int32_t *bestDist);
+/* N3: ORBmatcher::SearchBySim3, ORBmatcher.cc:1788-2012. */
+int orc_search_by_sim3(orc_frame *kf1, float logSf1, const uint8_t *valid1, const float *Xw1, const uint8_t *mpdesc1,
+                       const float *maxDist1, const float *minDist1, const float *R1w, const float *t1w, orc_frame *kf2, float logSf2,
+                       const uint8_t *valid2, const float *Xw2, const uint8_t *mpdesc2, const float *maxDist2, const float *minDist2,
+                       const float *R2w, const float *t2w, float s12, const float *R12, const float *t12, const float *cam1, float th,
+                       int32_t *matches12);
 /* N3: SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&), ORBmatcher.cc:839-979. */
 int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, float nnratio, int checkOri, int32_t *matches12);
 

@@ -532,3 +532,44 @@ def test_fuse_sim3_n3(pkg, oracle, synth, matcher):
     n_ref, bi_ref, bd_ref = oracle.fuse_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 4.0)
     assert n_gpu == n_ref and n_ref > 100
     assert np.array_equal(bi_gpu, bi_ref) and np.array_equal(bd_gpu, bd_ref)
+
+
+def test_search_by_sim3_n3(pkg, oracle, synth, matcher):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1788-2012): map points of KF1 searched in KF2 through the Sim3 and back, depth-range
+    gate, PredictScale, [lvl-1, lvl] window, TH_HIGH, mutual-consistency pass."""
+    (k0, d0), (k1, d1), offs, sf = make_frame_pair(pkg, oracle, synth, 3970)
+    rng = np.random.default_rng(47)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    cam = np.array([fx, fy, cx, cy], np.float32)
+    z = np.float32(5.0)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+    # KF1 at the origin; KF2 displaced so that a point seen at (u, v) in KF1 lands at (u + dx, v + dy) in KF2; s12 = 1 + eps
+    R1w, t1w = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    R2w, t2w = np.eye(3, dtype=np.float32), np.array([dx * z / fx, dy * z / fy, 0.0], np.float32)
+    s12 = np.float32(1.02)
+    R12 = np.eye(3, dtype=np.float32)
+    t12 = (-t2w * s12).astype(np.float32)                             # p1 = s12 * R12 * p2 + t12  ~  inverse of p2 = p1 + t2w
+
+    def backproject(k, tw):
+        Xc = np.stack([(k["x"] - np.float32(cx)) / np.float32(fx) * z, (k["y"] - np.float32(cy)) / np.float32(fy) * z, np.full(len(k), z, np.float32)], axis=1)
+        return (Xc - tw).astype(np.float32)                           # world point of the keypoint (R = I)
+
+    def side(k, d, Rw, tw):
+        Xw = backproject(k, tw)
+        dist = np.sqrt((Xw.astype(np.float64) ** 2).sum(axis=1)).astype(np.float32)
+        max_dist = (dist * sf[k["octave"]] * np.float32(1.1)).astype(np.float32)
+        min_dist = (max_dist / sf[-1]).astype(np.float32)
+        valid = (rng.random(len(k)) < 0.8).astype(np.uint8)           # pMP && !isBad && !alreadyMatched
+        return dict(sf=sf, log_sf=float(np.log(np.float32(1.2))), valid=valid, Xw=Xw, desc=d, max_dist=max_dist, min_dist=min_dist, Rw=Rw, tw=tw)
+
+    S1, S2 = side(k0, d0, R1w, t1w), side(k1, d1, R2w, t2w)
+    KF1, KF2 = pkg.FrameView(k0, d0, bounds), pkg.FrameView(k1, d1, bounds)
+    O1 = oracle.OracleFrame(k0["x"], k0["y"], k0["octave"], k0["angle"], d0, bounds, sf)
+    O2 = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
+    n_gpu, m_gpu = matcher.SearchBySim3(KF1, S1, KF2, S2, float(s12), R12, t12, cam, 7.5)
+    n_ref, m_ref = oracle.search_by_sim3(O1, S1["log_sf"], S1["valid"], S1["Xw"], d0, S1["max_dist"], S1["min_dist"], R1w, t1w,
+                                         O2, S2["log_sf"], S2["valid"], S2["Xw"], d1, S2["max_dist"], S2["min_dist"], R2w, t2w,
+                                         float(s12), R12, t12, cam, 7.5)
+    assert n_gpu == n_ref and n_ref > 100
+    assert np.array_equal(m_gpu, m_ref)
