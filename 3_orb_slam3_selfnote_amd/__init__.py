@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -120,6 +120,7 @@ def load(build_if_needed=True):
     L.orbm_fuse.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp]
     L.orbm_fuse_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
     L.orbm_search_by_sim3.argtypes = [vp] + [vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp] * 2 + [f32, vp, vp, vp, f32, vp]
+    L.orbm_distinctive_descriptors.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -613,6 +614,20 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_search_by_sim3 rc=%d" % rc)
         return rc, m12[:KF1.N]
+
+    def ComputeDistinctiveDescriptors(self, groups):
+        """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:350-436) for many map points at once.
+        groups: list of (N_p, 32) uint8 arrays (the descriptors observing map point p).  Returns BestIdx per map point."""
+        start = np.zeros(len(groups) + 1, np.int32)
+        for i, g in enumerate(groups):
+            start[i + 1] = start[i] + len(g)
+        desc = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8).reshape(-1, 32) for g in groups]) if len(groups) else np.zeros((0, 32), np.uint8))
+        best = np.full(max(len(groups), 1), -1, np.int32)
+        rc = self.L.orbm_distinctive_descriptors(self.m, len(groups), _p(start), _p(desc), _p(best))
+        self._check(rc, "orbm_distinctive_descriptors")
+        if rc < 0:
+            raise OrbError("orbm_distinctive_descriptors rc=%d" % rc)
+        return best[:len(groups)]
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

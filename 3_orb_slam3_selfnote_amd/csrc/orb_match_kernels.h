@@ -929,6 +929,50 @@ __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
   }
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:350-436): among the N descriptors observing a map point, the one
+// with the least MEDIAN Hamming distance to the others (median = sorted row [int(0.5*(N-1))], first minimum wins).
+// One wavefront per map point: rows in order; the lanes hold the row's distances (j = lane + 64 t) and the k-th smallest
+// is found by bisection on the value with ballot counts - no sort, no N x N matrix.
+#define DISTINCT_MAXT 16   // N <= 1024 observations per map point
+__global__ __launch_bounds__(256) void k_distinctive(const uint32_t *desc, const int32_t *start, int nmp, int32_t *best) {
+  const int lane = threadIdx.x & 63;
+  const int mp = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (mp >= nmp) return;
+  const int s0 = start[mp], N = start[mp + 1] - s0;
+  if (N <= 0) { if (lane == 0) best[mp] = -1; return; }
+  const int nt = (N + 63) >> 6;
+  const int k = (int)(0.5 * (double)(N - 1));                     // vDists[0.5*(N-1)], MapPoint.cc:423
+  int bestMedian = 0x7fffffff, bestIdx = 0;
+  for (int i = 0; i < N; i++) {
+    uint32_t di[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) di[w] = desc[(size_t)(s0 + i) * 8 + w];
+    int d[DISTINCT_MAXT];
+#pragma unroll
+    for (int t = 0; t < DISTINCT_MAXT; t++) {
+      d[t] = 0x7fff;                                              // beyond every real distance: never counted
+      const int j = lane + 64 * t;
+      if (t < nt && j < N) {
+        int dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) dist += __popc(di[w] ^ desc[(size_t)(s0 + j) * 8 + w]);
+        d[t] = dist;
+      }
+    }
+    int lo = 0, hi = 256;                                         // smallest v with #{j : d_ij <= v} >= k + 1
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+#pragma unroll
+      for (int t = 0; t < DISTINCT_MAXT; t++)
+        if (t < nt) cnt += __popcll(__ballot(d[t] <= mid));
+      if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    if (lo < bestMedian) { bestMedian = lo; bestIdx = i; }        // :424-428
+  }
+  if (lane == 0) best[mp] = bestIdx;
+}
+
 // K8 brute force: dist[i][j] = popcount(q_i ^ c_j).  Candidates staged through LDS in 256-descriptor (8 KB) chunks.
 __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t *q, int nq, const uint32_t *c, int nc, uint16_t *dist) {
   __shared__ uint32_t sC[256 * 9];  // +1 word pad per descriptor: conflict-free column reads

@@ -1790,6 +1790,29 @@ int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const or
   return bow_core(m, kf1, kf2, nnratio, checkOri, true, matches12);
 }
 
+int orbm_distinctive_descriptors(orbm_t *m, int nmp, const int32_t *start, const uint8_t *desc, int32_t *best) {
+  if (!m || nmp < 0 || (nmp > 0 && (!start || !best))) return ORBX_E_ARG;
+  if (nmp == 0) return 0;
+  const int total = start[nmp];
+  for (int i = 0; i < nmp; i++) {
+    const int n = start[i + 1] - start[i];
+    if (n < 0 || n > 64 * DISTINCT_MAXT) { m->err = "ComputeDistinctiveDescriptors: more than 1024 observations of one map point"; return ORBX_E_ARG; }
+  }
+  if (total > 0 && !desc) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  MCHECK(m, m->d_a.reserve(std::max<size_t>(32 * (size_t)total, 4)));
+  MCHECK(m, m->d_b.reserve(sizeof(int32_t) * (size_t)(nmp + 1)));
+  MCHECK(m, m->d_c.reserve(sizeof(int32_t) * (size_t)nmp));
+  if (total > 0) MCHECK(m, hipMemcpyAsync(m->d_a.p, desc, 32 * (size_t)total, hipMemcpyHostToDevice, s));
+  MCHECK(m, hipMemcpyAsync(m->d_b.p, start, sizeof(int32_t) * (size_t)(nmp + 1), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_distinctive, dim3((nmp + 3) / 4), dim3(256), 0, s, (const uint32_t *)m->d_a.p, (const int32_t *)m->d_b.p, nmp, (int32_t *)m->d_c.p);
+  MCHECK(m, hipGetLastError());
+  MCHECK(m, hipMemcpyAsync(best, m->d_c.p, sizeof(int32_t) * (size_t)nmp, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  return 0;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

@@ -343,6 +343,12 @@ int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe
 int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float nnratio, int checkOri,
                                  int32_t *matches12);
 
+/* void MapPoint::ComputeDistinctiveDescriptors()  (MapPoint.cc:350-436), batched over map points: the descriptors that
+ * observe map point p are desc[32*start[p] .. 32*start[p+1]) in the order the reference collects them (observations map
+ * order, left index before right index); best[p] (out) = BestIdx within that group (-1 for an empty group), i.e.
+ * mDescriptor = vDescriptors[best[p]].  At most 1024 observations per map point.  Returns 0. */
+int orbm_distinctive_descriptors(orbm_t *m, int nmp, const int32_t *start, const uint8_t *desc, int32_t *best);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

@@ -472,6 +472,14 @@ def search_by_sim3(F1, log_sf1, valid1, Xw1, desc1, maxd1, mind1, R1w, t1w, F2, 
     return n, m12[:F1.N]
 
 
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:350-436): BestIdx among the rows of desc (N x 32)."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    L = lib()
+    L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+    return L.orc_distinctive_descriptor(_p(desc), len(desc))
+
+
 def undistort_points(xy, K, D):
     xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
     K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)

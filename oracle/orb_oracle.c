@@ -2107,3 +2107,28 @@ int orc_search_by_sim3(orc_frame *kf1, float logSf1, const uint8_t *valid1, cons
   free(vnMatch1); free(vnMatch2);
   return nFound;
 }
+
+/* N3: MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:350-436: BestIdx of one group of N descriptors. */
+static int cmp_int(const void *a, const void *b) { const int x = *(const int *)a, y = *(const int *)b; return x < y ? -1 : (x > y ? 1 : 0); }
+int orc_distinctive_descriptor(const uint8_t *desc, int N) {
+  if (N <= 0) return -1;
+  float *D = (float *)malloc(sizeof(float) * (size_t)N * (size_t)N);
+  for (int i = 0; i < N; i++) {
+    D[(size_t)i * N + i] = 0;
+    for (int j = i + 1; j < N; j++) {
+      const int distij = orc_descriptor_distance(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+      D[(size_t)i * N + j] = (float)distij;
+      D[(size_t)j * N + i] = (float)distij;
+    }
+  }
+  int BestMedian = 2147483647, BestIdx = 0;
+  int *v = (int *)malloc(sizeof(int) * (size_t)N);
+  for (int i = 0; i < N; i++) {
+    for (int j = 0; j < N; j++) v[j] = (int)D[(size_t)i * N + j];
+    qsort(v, (size_t)N, sizeof(int), cmp_int);
+    const int median = v[(int)(0.5 * (double)(N - 1))];
+    if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+  }
+  free(v); free(D);
+  return BestIdx;
+}

@@ -204,6 +204,8 @@ int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const
 int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
                   const float *maxDist, const float *minDist, const float *Scw, const float *cam, float logScaleFactor, float th,
                   int32_t *bestIdx, int32_t *bestDist);
+/* N3: MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:350-436 (BestIdx of one group). */
+int orc_distinctive_descriptor(const uint8_t *desc, int N);
 /* N3: ORBmatcher::SearchBySim3, ORBmatcher.cc:1788-2012. */
 int orc_search_by_sim3(orc_frame *kf1, float logSf1, const uint8_t *valid1, const float *Xw1, const uint8_t *mpdesc1,
                        const float *maxDist1, const float *minDist1, const float *R1w, const float *t1w, orc_frame *kf2, float logSf2,

@@ -573,3 +573,23 @@ def test_search_by_sim3_n3(pkg, oracle, synth, matcher):
                                          float(s12), R12, t12, cam, 7.5)
     assert n_gpu == n_ref and n_ref > 100
     assert np.array_equal(m_gpu, m_ref)
+
+
+def test_compute_distinctive_descriptors_n3(pkg, oracle, synth, matcher):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:350-436): least-median descriptor of each observation group,
+    incl. N = 1, 2 (median index 0), even / odd N, ties (first wins), a group above 64 and one above 256 observations."""
+    rng = np.random.default_rng(53)
+    base, _ = synth.make_descriptor_sets(5300, n=400)
+    groups = []
+    for n in [1, 2, 3, 4, 7, 16, 33, 64, 65, 130, 300] + list(rng.integers(1, 40, size=60)):
+        centre = base[rng.integers(0, len(base))]
+        g = np.repeat(centre[None, :], n, axis=0).copy()
+        flips = rng.random((n, 256)) < rng.uniform(0.02, 0.2)
+        g ^= np.packbits(flips, axis=1, bitorder="little")
+        if n > 3 and rng.random() < 0.5:
+            g[n // 2] = g[0]                                          # exact duplicates -> tied medians
+        groups.append(g)
+    groups.append(np.zeros((0, 32), np.uint8))                        # a map point without usable observations
+    got = matcher.ComputeDistinctiveDescriptors(groups)
+    ref = np.array([oracle.distinctive_descriptor(g) if len(g) else -1 for g in groups], np.int32)
+    assert np.array_equal(got, ref)
