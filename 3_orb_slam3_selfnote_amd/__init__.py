@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -121,6 +121,7 @@ def load(build_if_needed=True):
     L.orbm_fuse_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
     L.orbm_search_by_sim3.argtypes = [vp] + [vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp] * 2 + [f32, vp, vp, vp, f32, vp]
     L.orbm_distinctive_descriptors.argtypes = [vp, i32, vp, vp, vp]
+    L.orbm_knn_match2.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -628,6 +629,17 @@ class ORBmatcher:
         if rc < 0:
             raise OrbError("orbm_distinctive_descriptors rc=%d" % rc)
         return best[:len(groups)]
+
+    def knnMatch2(self, query, train):
+        """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) (Frame.cc:1246).  Returns (idx[nq, 2], dist[nq, 2])."""
+        query, train = np.ascontiguousarray(query, dtype=np.uint8), np.ascontiguousarray(train, dtype=np.uint8)
+        nq = len(query)
+        idx, dist = np.full((max(nq, 1), 2), -1, np.int32), np.full((max(nq, 1), 2), -1, np.int32)
+        rc = self.L.orbm_knn_match2(self.m, _p(query), nq, _p(train), len(train), _p(idx), _p(dist))
+        self._check(rc, "orbm_knn_match2")
+        if rc < 0:
+            raise OrbError("orbm_knn_match2 rc=%d" % rc)
+        return idx[:nq], dist[:nq]
 
     def SearchByProjectionKeyFrame(self, CurrentFrame, scale_factors, log_scale_factor, valid, Xw, mp_desc, kf_angle, max_dist,
                                    min_dist, Tcw, cam_type, cam_params, th, ORBdist):

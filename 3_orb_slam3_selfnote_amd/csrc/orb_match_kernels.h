@@ -973,6 +973,33 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint32_t *desc, const
   if (lane == 0) best[mp] = bestIdx;
 }
 
+// cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, matches, 2) as used by Frame::ComputeStereoFishEyeMatches
+// (Frame.cc:1246): the two nearest train descriptors of every query descriptor.  One wavefront per query; ties in
+// distance are ordered by train index (the caller's Lowe ratio test, :1252, cannot tell the orders apart).
+__global__ __launch_bounds__(256) void k_knn2(const uint32_t *q, int nq, const uint32_t *c, int nc, int32_t *idx2, int32_t *dist2) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (qi >= nq) return;
+  uint32_t qd[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) qd[w] = q[(size_t)qi * 8 + w];
+  unsigned long long b1 = ~0ull, b2 = ~0ull;
+  for (int j = lane; j < nc; j += 64) {
+    int d = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) d += __popc(qd[w] ^ c[(size_t)j * 8 + w]);
+    const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)(uint32_t)j;
+    if (key < b1) { b2 = b1; b1 = key; }
+    else if (key < b2) b2 = key;
+  }
+  const unsigned long long g1 = wave_min_key(b1);
+  const unsigned long long g2 = wave_min_key(b1 == g1 ? b2 : b1);
+  if (lane == 0) {
+    idx2[2 * qi] = g1 != ~0ull ? (int32_t)(uint32_t)g1 : -1; dist2[2 * qi] = g1 != ~0ull ? (int32_t)(g1 >> 32) : -1;
+    idx2[2 * qi + 1] = g2 != ~0ull ? (int32_t)(uint32_t)g2 : -1; dist2[2 * qi + 1] = g2 != ~0ull ? (int32_t)(g2 >> 32) : -1;
+  }
+}
+
 // K8 brute force: dist[i][j] = popcount(q_i ^ c_j).  Candidates staged through LDS in 256-descriptor (8 KB) chunks.
 __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t *q, int nq, const uint32_t *c, int nc, uint16_t *dist) {
   __shared__ uint32_t sC[256 * 9];  // +1 word pad per descriptor: conflict-free column reads

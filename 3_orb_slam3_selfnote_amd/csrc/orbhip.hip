@@ -1813,6 +1813,26 @@ int orbm_distinctive_descriptors(orbm_t *m, int nmp, const int32_t *start, const
   return 0;
 }
 
+int orbm_knn_match2(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, int32_t *idx2, int32_t *dist2) {
+  if (!m || nq < 0 || nc < 0 || (nq > 0 && (!q || !idx2 || !dist2)) || (nc > 0 && !c)) return ORBX_E_ARG;
+  if (nq == 0) return 0;
+  if (nc == 0) { for (int i = 0; i < 2 * nq; i++) { idx2[i] = -1; dist2[i] = -1; } return 0; }
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  MCHECK(m, m->d_a.reserve(32 * (size_t)nq));
+  MCHECK(m, m->d_b.reserve(32 * (size_t)nc));
+  MCHECK(m, m->d_c.reserve(sizeof(int32_t) * 4 * (size_t)nq));
+  MCHECK(m, hipMemcpyAsync(m->d_a.p, q, 32 * (size_t)nq, hipMemcpyHostToDevice, s));
+  MCHECK(m, hipMemcpyAsync(m->d_b.p, c, 32 * (size_t)nc, hipMemcpyHostToDevice, s));
+  int32_t *d_idx = (int32_t *)m->d_c.p, *d_dist = d_idx + 2 * (size_t)nq;
+  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc, d_idx, d_dist);
+  MCHECK(m, hipGetLastError());
+  MCHECK(m, hipMemcpyAsync(idx2, d_idx, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipMemcpyAsync(dist2, d_dist, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  return 0;
+}
+
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist) {
   if (!m || !q || !c || !dist || nq <= 0 || nc <= 0) return ORBX_E_ARG;
   MCHECK(m, hipSetDevice(m->device));

@@ -349,6 +349,12 @@ int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const or
  * mDescriptor = vDescriptors[best[p]].  At most 1024 observations per map point.  Returns 0. */
 int orbm_distinctive_descriptors(orbm_t *m, int nmp, const int32_t *start, const uint8_t *desc, int32_t *best);
 
+/* cv::BFMatcher(cv::NORM_HAMMING).knnMatch(query, train, matches, 2) as called by Frame::ComputeStereoFishEyeMatches
+ * (Frame.cc:1246): idx2[2i..], dist2[2i..] = train index and distance of the nearest and second nearest train descriptor
+ * of query i (-1 where nc < 2).  Equal distances are ordered by train index; the only consumer (the ratio test of
+ * Frame.cc:1252) gives the same result for any tie order.  Host pointers.  Returns 0. */
+int orbm_knn_match2(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, int32_t *idx2, int32_t *dist2);
+
 /* Brute-force Hamming (K8): dist[i*nc + j] = popcount(q_i xor c_j); host pointers. */
 int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int nc, uint16_t *dist);
 

@@ -593,3 +593,16 @@ def test_compute_distinctive_descriptors_n3(pkg, oracle, synth, matcher):
     got = matcher.ComputeDistinctiveDescriptors(groups)
     ref = np.array([oracle.distinctive_descriptor(g) if len(g) else -1 for g in groups], np.int32)
     assert np.array_equal(got, ref)
+
+
+def test_knn_match2(pkg, matcher, synth):
+    """BFMatcher(NORM_HAMMING).knnMatch(k=2) (Frame.cc:1246): checked against numpy on the full distance matrix."""
+    q, c = synth.make_descriptor_sets(5400, n=700)
+    c = np.concatenate([c, c[:5]])                                    # duplicates: tied distances, ordered by train index
+    idx, dist = matcher.knnMatch2(q, c)
+    D = np.unpackbits(q[:, None, :] ^ c[None, :, :], axis=2).sum(axis=2).astype(np.int64)
+    order = np.argsort(D * (1 << 20) + np.arange(len(c))[None, :], axis=1)[:, :2]
+    assert np.array_equal(idx, order.astype(np.int32))
+    assert np.array_equal(dist, np.take_along_axis(D, order, axis=1).astype(np.int32))
+    i1, d1 = matcher.knnMatch2(q[:3], c[:1])
+    assert (i1[:, 0] == 0).all() and (i1[:, 1] == -1).all() and (d1[:, 1] == -1).all()
