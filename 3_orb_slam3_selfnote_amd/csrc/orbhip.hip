@@ -75,6 +75,7 @@ struct orbx_handle {
   // last call
   FrameParams last{};
   bool have_last = false;
+  DevBuf stereo[7];  // grow-only buffers of orbx_compute_stereo_matches
   // profiling
   bool profiling = false;
   hipEvent_t ev[8] = {};
@@ -181,6 +182,7 @@ void orbx_destroy(orbx_t *h) {
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
                     &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
+  for (DevBuf &b : h->stereo) b.release();
   if (h->ev_ok)
     for (auto &e : h->ev) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -632,6 +634,7 @@ struct orbm_handle {
   hipStream_t stream = nullptr;
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   DevBuf d_partner, d_qside, d_qany;
+  DevBuf scratch[8];  // grow-only buffers of the per-node / per-map-point entry points (SearchByBoW, ...)
   // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
   // orbm_search_by_projection_batch_device): device pointers
   struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; int init_th_low = -1; const float *fuse_inv_sigma2 = nullptr; } ext;
@@ -671,7 +674,8 @@ void orbm_destroy(orbm_t *m) {
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
-                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany};
+                    &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany, &m->scratch[0], &m->scratch[1], &m->scratch[2], &m->scratch[3],
+                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7]};
   for (DevBuf *b : bufs) b->release();
   if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); (void)hipEventDestroy(m->ev[2]); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1659,8 +1663,7 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
   XCHECK(hl, hipSetDevice(hl->device));
   hipStream_t s = hl->stream;
   XCHECK(hl, hipStreamSynchronize(hr->stream));
-  DevBuf bufs[7];
-  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 7; i++) b[i].release(); } } guard{bufs};
+  DevBuf *bufs = hl->stereo;
   const size_t sz[7] = {sizeof(orbx_keypoint_t) * (size_t)nL, sizeof(orbx_keypoint_t) * (size_t)nR, 32 * (size_t)nL, 32 * (size_t)nR,
                         sizeof(float) * (size_t)nL, sizeof(float) * (size_t)nL, sizeof(int32_t) * (size_t)nL};
   const void *src[4] = {keysL, keysR, descL, descR};
@@ -1735,8 +1738,7 @@ static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t 
   MCHECK(m, hipSetDevice(m->device));
   hipStream_t s = m->stream;
   const size_t nidxKF = (size_t)kf->node_start[kf->n_nodes], nidxF = (size_t)f->node_start[f->n_nodes];
-  DevBuf bufs[8];
-  struct Guard { DevBuf *b; ~Guard() { for (int i = 0; i < 8; i++) b[i].release(); } } guard{bufs};
+  DevBuf *bufs = m->scratch;
   const size_t sz[8] = {32 * (size_t)kf->n, 32 * (size_t)f->n, (size_t)kf->n, sizeof(int32_t) * nidxKF, sizeof(int32_t) * nidxF,
                         sizeof(BowItem) * items.size(), sizeof(int32_t) * (size_t)nout, kf_kf ? (size_t)f->n : 0};
   const void *src[8] = {kf->descriptors, f->descriptors, kf->has_mappoint, kf->node_idx, f->node_idx, items.data(), out, kf_kf ? f->has_mappoint : nullptr};
