@@ -924,6 +924,27 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   int pitch;
   const uint8_t *img = level_plane(P, frame, level, pitch);
   const uint8_t *centre = img + (size_t)Y * pitch + X;
+  // The 37x37 blurred patch the 512 steered test points can fall into (|rotated offset| <= 18) is requested NOW, together
+  // with the disc gathers, as 37 rows x 10 aligned dwords into this wave's LDS slice: the BRIEF gathers then never leave
+  // the CU and the wave pays one global round trip less.  Keypoints are >= 19 px inside the level, so rows Y-18..Y+18 and
+  // columns X-18..X+18 exist; the up to 3 extra bytes of the aligned dwords stay inside the plane's pitch padding / next row.
+  __shared__ uint32_t sPatch[4][37 * 10];
+  uint32_t *myPatch = sPatch[threadIdx.x >> 6];
+  const int px0 = (X - 18) & ~3, pox = (X - 18) - px0;
+  {
+    const uint8_t *brow = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)(Y - 18) * G.bpitch + px0;
+    uint32_t pv[6];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const int idx = lane + 64 * t, r = idx / 10, d = idx - r * 10;
+      pv[t] = idx < 370 ? *reinterpret_cast<const uint32_t *>(brow + (size_t)r * G.bpitch + 4 * d) : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const int idx = lane + 64 * t;
+      if (idx < 370) myPatch[idx] = pv[t];
+    }
+  }
   int m10 = 0, m01 = 0;
   int dv[12], du[12], dval[12];
   {
@@ -946,8 +967,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   const float arad = angle * factorPI;
   const float a = orbsc::ref_cosf(arad), b = orbsc::ref_sinf(arad);
-  const uint8_t *bc = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)Y * G.bpitch + X;
-  const int bp = G.bpitch;
+  const uint8_t *bc = reinterpret_cast<const uint8_t *>(myPatch) + 18 * 40 + pox + 18;   // patch centre; row pitch 40 B
+  constexpr int bp = 40;
   unsigned long long bits[4];
   int o0[4], o1[4];
 #pragma unroll
