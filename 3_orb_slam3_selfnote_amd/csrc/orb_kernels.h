@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const size_t sRowsOff = ((size_t)G.w * 8 + 15) & ~(size_t)15;
   uint8_t *sRows = smem_rs + sRowsOff;   // [nsrc][smemRowBytes]
   for (int i = tid; i < G.w; i += 256) sX[i] = P.xtab[G.xtabBase + i];
+  // the tile's y-coefficients go through LDS as well: the row loop below then has no global load in front of its gathers
+  __shared__ int2 sY[RESIZE_ROWS];
+  if (tid < nrows) sY[tid] = P.ytab[G.ytabBase + dy0 + tid];
   const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
   if (nsrc <= RESIZE_MAXSRC) {
     if (aligned) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   auto rows = [&](auto srcRow) {
     for (int q = tid; q < qw * nrows; q += 256) {
       const int ry = (int)__umulhi((uint32_t)q, mq), dx0 = (q - ry * qw) * 4, dy = dy0 + ry;
-      const int2 yt = P.ytab[G.ytabBase + dy];
+      const int2 yt = sY[ry];
       const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
       const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
       const auto S0 = srcRow(sy0), S1 = srcRow(sy1);
