@@ -76,6 +76,14 @@ struct orbx_handle {
   FrameParams last{};
   bool have_last = false;
   DevBuf stereo[7];  // grow-only buffers of orbx_compute_stereo_matches
+  // pinned host staging of the single-frame entry point (orbx_extract): pageable copies would serialise on HIP's own staging
+  void *pin_in = nullptr, *pin_out = nullptr;
+  size_t pin_in_bytes = 0, pin_out_bytes = 0;
+  // the per-frame sequence of orbx_extract (H2D, 13 launches, 3 D2H) captured once per configuration as a hipGraph:
+  // one submission per frame instead of 17
+  hipGraphExec_t graph = nullptr;
+  struct { int rows = 0, cols = 0, lap0 = 0, lap1 = 0, icap = 0; const void *pin_in = nullptr, *pin_out = nullptr, *d_img = nullptr, *d_okps = nullptr, *d_odesc = nullptr, *d_pyr = nullptr; } graph_key;
+  bool graph_ok = true;   // cleared (for good) if capture / instantiation fails: the plain path is used instead
   // profiling
   bool profiling = false;
   hipEvent_t ev[8] = {};
@@ -183,6 +191,9 @@ void orbx_destroy(orbx_t *h) {
                     &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
   for (DevBuf &b : h->stereo) b.release();
+  if (h->graph) (void)hipGraphExecDestroy(h->graph);
+  if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->ev_ok)
     for (auto &e : h->ev) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -523,19 +534,73 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
   XCHECK(h, h->d_okps.reserve(sizeof(orbx_keypoint_t) * (size_t)icap));
   XCHECK(h, h->d_odesc.reserve(32 * (size_t)icap));
   XCHECK(h, h->d_ocounts.reserve(sizeof(int32_t) * 2));
-  XCHECK(h, hipMemcpy2DAsync(h->d_img.p, dstride, image, stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, h->stream));
-  rc = orbx_extract_batch_device(h, (const uint8_t *)h->d_img.p, rows, cols, dstride, dstride * rows, 1, lap0, lap1,
-                                 (orbx_keypoint_t *)h->d_okps.p, (uint8_t *)h->d_odesc.p, (int32_t *)h->d_ocounts.p, icap, h->stream);
-  if (rc < 0) return rc;
-  int32_t counts[2] = {0, 0};
-  XCHECK(h, hipMemcpyAsync(counts, h->d_ocounts.p, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+  // pinned staging: one H2D, all kernels, three D2H and ONE synchronisation per frame
+  const size_t in_bytes = dstride * rows, kp_bytes = sizeof(orbx_keypoint_t) * (size_t)icap, de_bytes = 32 * (size_t)icap;
+  const size_t out_bytes = 16 + kp_bytes + de_bytes;
+  if (h->pin_in_bytes < in_bytes) {
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    h->pin_in = nullptr; h->pin_in_bytes = 0;
+    XCHECK(h, hipHostMalloc(&h->pin_in, in_bytes, hipHostMallocDefault));
+    h->pin_in_bytes = in_bytes;
+  }
+  if (h->pin_out_bytes < out_bytes) {
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    h->pin_out = nullptr; h->pin_out_bytes = 0;
+    XCHECK(h, hipHostMalloc(&h->pin_out, out_bytes, hipHostMallocDefault));
+    h->pin_out_bytes = out_bytes;
+  }
+  for (int y = 0; y < rows; y++) memcpy((uint8_t *)h->pin_in + (size_t)y * dstride, image + (size_t)y * stride, (size_t)cols);
+  uint8_t *po = (uint8_t *)h->pin_out;
+  auto enqueue = [&]() -> int {  // the whole per-frame sequence on h->stream
+    XCHECK(h, hipMemcpyAsync(h->d_img.p, h->pin_in, in_bytes, hipMemcpyHostToDevice, h->stream));
+    const int r = orbx_extract_batch_device(h, (const uint8_t *)h->d_img.p, rows, cols, dstride, dstride * rows, 1, lap0, lap1,
+                                            (orbx_keypoint_t *)h->d_okps.p, (uint8_t *)h->d_odesc.p, (int32_t *)h->d_ocounts.p, icap, h->stream);
+    if (r < 0) return r;
+    XCHECK(h, hipMemcpyAsync(po, h->d_ocounts.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, h->stream));
+    XCHECK(h, hipMemcpyAsync(po + 16, h->d_okps.p, kp_bytes, hipMemcpyDeviceToHost, h->stream));
+    XCHECK(h, hipMemcpyAsync(po + 16 + kp_bytes, h->d_odesc.p, de_bytes, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+  };
+  bool launched = false;
+  if (h->graph_ok && !h->profiling) {
+    auto &K = h->graph_key;
+    const bool same = h->graph && K.rows == rows && K.cols == cols && K.lap0 == lap0 && K.lap1 == lap1 && K.icap == icap && K.pin_in == h->pin_in &&
+                      K.pin_out == h->pin_out && K.d_img == h->d_img.p && K.d_okps == h->d_okps.p && K.d_odesc == h->d_odesc.p && K.d_pyr == h->d_pyr.p;
+    if (!same) {
+      if (h->graph) { (void)hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+      hipGraph_t g = nullptr;
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int r = enqueue();
+        const hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (r == 0 && e == hipSuccess && g && hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0) == hipSuccess) {
+          K.rows = rows; K.cols = cols; K.lap0 = lap0; K.lap1 = lap1; K.icap = icap; K.pin_in = h->pin_in; K.pin_out = h->pin_out;
+          K.d_img = h->d_img.p; K.d_okps = h->d_okps.p; K.d_odesc = h->d_odesc.p; K.d_pyr = h->d_pyr.p;
+        } else {
+          h->graph = nullptr;
+          h->graph_ok = false;
+          (void)hipGetLastError();
+        }
+        if (g) (void)hipGraphDestroy(g);
+      } else {
+        h->graph_ok = false;
+        (void)hipGetLastError();
+      }
+    }
+    if (h->graph) {
+      XCHECK(h, hipGraphLaunch(h->graph, h->stream));
+      launched = true;
+    }
+  }
+  if (!launched) { rc = enqueue(); if (rc < 0) return rc; }
   XCHECK(h, hipStreamSynchronize(h->stream));
+  int32_t counts[2];
+  memcpy(counts, po, sizeof(counts));
   *n_out = counts[0];
   if (counts[0] > cap) return ORBX_E_CAP;
   if (counts[0] > 0) {
     if (!keypoints || !descriptors) return ORBX_E_ARG;
-    XCHECK(h, hipMemcpy(keypoints, h->d_okps.p, sizeof(orbx_keypoint_t) * (size_t)counts[0], hipMemcpyDeviceToHost));
-    XCHECK(h, hipMemcpy(descriptors, h->d_odesc.p, 32 * (size_t)counts[0], hipMemcpyDeviceToHost));
+    memcpy(keypoints, po + 16, sizeof(orbx_keypoint_t) * (size_t)counts[0]);
+    memcpy(descriptors, po + 16 + kp_bytes, 32 * (size_t)counts[0]);
   }
   return counts[1];
 }
