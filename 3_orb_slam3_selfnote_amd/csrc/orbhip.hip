@@ -699,6 +699,8 @@ struct orbm_handle {
   hipStream_t stream = nullptr;
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   DevBuf d_partner, d_qside, d_qany;
+  DevBuf d_block;     // inputs + outputs of one host-pointer search, one block (see search_host)
+  void *pin = nullptr; size_t pin_bytes = 0;   // its pinned host mirror
   DevBuf scratch[8];  // grow-only buffers of the per-node / per-map-point entry points (SearchByBoW, ...)
   // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
   // orbm_search_by_projection_batch_device): device pointers
@@ -740,8 +742,9 @@ void orbm_destroy(orbm_t *m) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
                     &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany, &m->scratch[0], &m->scratch[1], &m->scratch[2], &m->scratch[3],
-                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7]};
+                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block};
   for (DevBuf *b : bufs) b->release();
+  if (m->pin) (void)hipHostFree(m->pin);
   if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); (void)hipEventDestroy(m->ev[2]); }
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -958,66 +961,74 @@ static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q
   }
   MCHECK(m, hipSetDevice(m->device));
   hipStream_t s = m->stream;
-#define UP(buf, src, bytes)                                                               \
-  do {                                                                                    \
-    MCHECK(m, (buf).reserve(bytes));                                                      \
-    MCHECK(m, hipMemcpyAsync((buf).p, (src), (bytes), hipMemcpyHostToDevice, s));         \
-  } while (0)
-  UP(m->d_kp, f->keys_un, sizeof(orbx_keypoint_t) * (size_t)n);
-  UP(m->d_desc, f->descriptors, 32 * (size_t)n);
-  if (f->u_right) UP(m->d_ur, f->u_right, sizeof(float) * (size_t)n);
-  UP(m->d_qdesc, q->descriptors, 32 * (size_t)nq);
-  UP(m->d_qf[0], q->u, sizeof(float) * (size_t)nq);
-  UP(m->d_qf[1], q->v, sizeof(float) * (size_t)nq);
-  UP(m->d_qf[2], q->radius, sizeof(float) * (size_t)nq);
-  if (q->u_r) UP(m->d_qf[3], q->u_r, sizeof(float) * (size_t)nq);
-  UP(m->d_qi[0], q->min_level, sizeof(int32_t) * (size_t)nq);
-  UP(m->d_qi[1], q->max_level, sizeof(int32_t) * (size_t)nq);
-  if (q->flags) UP(m->d_qfl, q->flags, (size_t)nq);
-  UP(m->d_slot, slot, sizeof(int32_t) * (size_t)n);
-  UP(m->d_sobs, slot_obs, (size_t)n);
+  // All inputs travel as ONE pinned block -> one H2D copy, all outputs as one block -> one D2H copy, one synchronisation
+  // (a dozen pageable copies would each stage and synchronise on their own).
+  struct Part { const void *src; size_t bytes, off; };
+  size_t total = 0;
+  auto part = [&](const void *src, size_t bytes) { Part p{src, bytes, total}; total += (bytes + 255) & ~(size_t)255; return p; };
+  const Part pKp = part(f->keys_un, sizeof(orbx_keypoint_t) * (size_t)n), pDesc = part(f->descriptors, 32 * (size_t)n);
+  const Part pUr = part(f->u_right, f->u_right ? sizeof(float) * (size_t)n : 0);
+  const Part pQd = part(q->descriptors, 32 * (size_t)nq), pQu = part(q->u, sizeof(float) * (size_t)nq), pQv = part(q->v, sizeof(float) * (size_t)nq);
+  const Part pQr = part(q->radius, sizeof(float) * (size_t)nq), pQur = part(q->u_r, q->u_r ? sizeof(float) * (size_t)nq : 0);
+  const Part pMinl = part(q->min_level, sizeof(int32_t) * (size_t)nq), pMaxl = part(q->max_level, sizeof(int32_t) * (size_t)nq);
+  const Part pFl = part(q->flags, q->flags ? (size_t)nq : 0);
+  const Part pPartner = part(ext ? ext->partner : nullptr, ext && ext->partner ? sizeof(int32_t) * (size_t)n : 0);
+  const Part pSide = part(ext ? ext->qside : nullptr, ext && ext->qside ? (size_t)nq : 0);
+  const size_t in_total = total;
+  // in/out and out-only arrays behind the inputs (same device block; downloaded as one range)
+  const size_t out_off = total;
+  const Part pSlot = part(slot, sizeof(int32_t) * (size_t)n), pSobs = part(slot_obs, (size_t)n);
+  const size_t upload_total = total;
+  const Part pMoq = part(nullptr, sizeof(int32_t) * (size_t)nq), pBd = part(nullptr, sizeof(int32_t) * (size_t)nq), pNm = part(nullptr, sizeof(int32_t));
+  const Part pAny = part(nullptr, ext && ext->couple == 2 ? (size_t)nq : 0);
+  (void)in_total;
+  if (m->pin_bytes < total) {
+    if (m->pin) (void)hipHostFree(m->pin);
+    m->pin = nullptr; m->pin_bytes = 0;
+    MCHECK(m, hipHostMalloc(&m->pin, total + (total >> 2), hipHostMallocDefault));
+    m->pin_bytes = total + (total >> 2);
+  }
+  MCHECK(m, m->d_block.reserve(total + (total >> 2)));
+  uint8_t *hp = (uint8_t *)m->pin, *dp = (uint8_t *)m->d_block.p;
+  for (const Part *p : {&pKp, &pDesc, &pUr, &pQd, &pQu, &pQv, &pQr, &pQur, &pMinl, &pMaxl, &pFl, &pPartner, &pSide, &pSlot, &pSobs})
+    if (p->bytes) memcpy(hp + p->off, p->src, p->bytes);
+  MCHECK(m, hipMemcpyAsync(dp, hp, upload_total, hipMemcpyHostToDevice, s));
   m->ext = {};
   if (ext) {
-    if (ext->partner) UP(m->d_partner, ext->partner, sizeof(int32_t) * (size_t)n);
-    if (ext->qside) UP(m->d_qside, ext->qside, (size_t)nq);
-    if (ext->couple == 2) MCHECK(m, m->d_qany.reserve((size_t)nq));
     m->ext.nleft = ext->nleft;
-    m->ext.partner = ext->partner ? (const int32_t *)m->d_partner.p : nullptr;
-    m->ext.qside = ext->qside ? (const uint8_t *)m->d_qside.p : nullptr;
+    m->ext.partner = ext->partner ? (const int32_t *)(dp + pPartner.off) : nullptr;
+    m->ext.qside = ext->qside ? (const uint8_t *)(dp + pSide.off) : nullptr;
     m->ext.couple = ext->couple;
     m->ext.serial = ext->serial;
-    m->ext.qany = ext->couple == 2 ? (uint8_t *)m->d_qany.p : nullptr;
+    m->ext.qany = ext->couple == 2 ? (uint8_t *)(dp + pAny.off) : nullptr;
     m->ext.init_th_low = ext->init_th_low;
     m->ext.fuse_inv_sigma2 = ext->fuse_inv_sigma2;   // host array of 16 floats, copied into the kernel arguments at launch
   }
-#undef UP
-  MCHECK(m, m->d_moq.reserve(sizeof(int32_t) * (size_t)nq));
-  MCHECK(m, m->d_bd.reserve(sizeof(int32_t) * (size_t)nq));
-  MCHECK(m, m->d_nm.reserve(sizeof(int32_t)));
   orbm_frame_t df = *f;
-  df.keys_un = (const orbx_keypoint_t *)m->d_kp.p;
-  df.descriptors = (const uint8_t *)m->d_desc.p;
-  df.u_right = f->u_right ? (const float *)m->d_ur.p : nullptr;
+  df.keys_un = (const orbx_keypoint_t *)(dp + pKp.off);
+  df.descriptors = dp + pDesc.off;
+  df.u_right = f->u_right ? (const float *)(dp + pUr.off) : nullptr;
   orbm_queries_t dq = *q;
-  dq.descriptors = (const uint8_t *)m->d_qdesc.p;
-  dq.u = (const float *)m->d_qf[0].p;
-  dq.v = (const float *)m->d_qf[1].p;
-  dq.radius = (const float *)m->d_qf[2].p;
-  dq.u_r = q->u_r ? (const float *)m->d_qf[3].p : nullptr;
-  dq.min_level = (const int32_t *)m->d_qi[0].p;
-  dq.max_level = (const int32_t *)m->d_qi[1].p;
-  dq.flags = q->flags ? (const uint8_t *)m->d_qfl.p : nullptr;
+  dq.descriptors = dp + pQd.off;
+  dq.u = (const float *)(dp + pQu.off);
+  dq.v = (const float *)(dp + pQv.off);
+  dq.radius = (const float *)(dp + pQr.off);
+  dq.u_r = q->u_r ? (const float *)(dp + pQur.off) : nullptr;
+  dq.min_level = (const int32_t *)(dp + pMinl.off);
+  dq.max_level = (const int32_t *)(dp + pMaxl.off);
+  dq.flags = q->flags ? (const uint8_t *)(dp + pFl.off) : nullptr;
   int rc = orbm_search_by_projection_batch_device(m, &df, n, nullptr, 0, &dq, nq, nullptr, 0, 1, nnratio, th_dist, use_second,
-                                                  (int32_t *)m->d_slot.p, (uint8_t *)m->d_sobs.p, (int32_t *)m->d_moq.p,
-                                                  (int32_t *)m->d_bd.p, (int32_t *)m->d_nm.p, s);
+                                                  (int32_t *)(dp + pSlot.off), dp + pSobs.off, (int32_t *)(dp + pMoq.off),
+                                                  (int32_t *)(dp + pBd.off), (int32_t *)(dp + pNm.off), s);
   if (rc < 0) return rc;
-  int32_t nm = 0;
-  MCHECK(m, hipMemcpyAsync(slot, m->d_slot.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
-  MCHECK(m, hipMemcpyAsync(slot_obs, m->d_sobs.p, (size_t)n, hipMemcpyDeviceToHost, s));
-  if (match_of_query) MCHECK(m, hipMemcpyAsync(match_of_query, m->d_moq.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
-  if (best_dist) MCHECK(m, hipMemcpyAsync(best_dist, m->d_bd.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost, s));
-  MCHECK(m, hipMemcpyAsync(&nm, m->d_nm.p, sizeof(nm), hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipMemcpyAsync(hp + out_off, dp + out_off, pNm.off + sizeof(int32_t) - out_off, hipMemcpyDeviceToHost, s));
   MCHECK(m, hipStreamSynchronize(s));
+  memcpy(slot, hp + pSlot.off, pSlot.bytes);
+  memcpy(slot_obs, hp + pSobs.off, pSobs.bytes);
+  if (match_of_query) memcpy(match_of_query, hp + pMoq.off, pMoq.bytes);
+  if (best_dist) memcpy(best_dist, hp + pBd.off, pBd.bytes);
+  int32_t nm = 0;
+  memcpy(&nm, hp + pNm.off, sizeof(nm));
   return nm;
 }
 
