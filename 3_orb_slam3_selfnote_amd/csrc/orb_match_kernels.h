@@ -180,6 +180,14 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   // GetFeaturesInArea's level filter (Frame.cc:779, :794-801) as a closed interval; open ends when it is disabled
   const int minlE = w.live && w.checkLevels ? w.minl : -1000;
   const int maxlE = w.live && w.checkLevels && w.maxl >= 0 ? w.maxl : 1000;
+  // The three range tests (octave, grid column, grid row) as ONE byte-parallel comparison: candidates carry
+  // octave | gx << 8 | gy << 16 in `bits`; with bit 7 of every byte pre-set a byte-wise subtraction keeps that bit iff
+  // no borrow occurred, i.e. iff the byte is >= its bound.  All operands are < 128 (gx < 64, gy < 48, octave < 16; open
+  // ends clamp to 0 / 127), so no borrow crosses a byte.  Keypoints outside the grid may carry larger bytes; they are
+  // rejected by their usable / in-grid bit whatever the comparison yields.
+  auto c7 = [](int v) { return (uint32_t)min(max(v, 0), 127); };
+  const uint32_t LO = c7(minlE) | (c7(w.cx0) << 8) | (c7(w.cy0) << 16);
+  const uint32_t HI7 = (c7(maxlE) | (c7(w.cx1) << 8) | (c7(w.cy1) << 16)) | 0x808080u;
   for (int base = 0; base < n; base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
     __syncthreads();
@@ -201,13 +209,14 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
         const CandMeta cm = sMeta[c];
         // cand_passes() in sign-bit arithmetic (one compare at the end instead of a dozen compare/and chains):
         // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
-        const int gx = (cm.bits >> 8) & 0xff, gy = (cm.bits >> 16) & 0xff, oct = cm.bits & 0xff;
-        int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct);
+        const int oct = cm.bits & 0xff;
+        const uint32_t G = cm.bits & 0xffffffu;
+        const uint32_t inRange = ((G | 0x808080u) - LO) & (HI7 - G) & 0x808080u;   // bit 7 of byte b set iff LO_b <= G_b <= HI_b
+        const int geo = (int)(inRange ^ 0x808080u) - 1;                              // negative iff all three ranges hold
         const int fpass = __float_as_int(fabsf(cm.x - w.u) - w.r) & __float_as_int(fabsf(cm.y - w.v) - w.r);
         const bool sok = !STEREO || (base + c >= nleft) == sideR;       // candidate index is uniform: a mask select
-        if (STEREO && wantAny) any = any || (sok && (fpass & ~(viol | ~(int)(cm.bits << 6))) < 0);  // GetFeaturesInArea alone (bit 25 = in grid)
-        viol |= ~(int)(cm.bits << 7);                                   // bit 24 = usable (in grid, not pre-occupied)
-        bool ok = sok && (fpass & ~viol) < 0;
+        if (STEREO && wantAny) any = any || (sok && (fpass & geo & (int)(cm.bits << 6)) < 0);  // GetFeaturesInArea alone (bit 25 = in grid)
+        bool ok = sok && (fpass & geo & (int)(cm.bits << 7)) < 0;      // bit 24 = usable (in grid, not pre-occupied)
         if (UR) ok = ok && !(cm.ur > 0.f && fabsf(w.ur - cm.ur) > w.r);        // ORBmatcher.cc:93-98, :2139-2146
         if (MODE == SCAN_FUSE) {                                          // ORBmatcher.cc:1585-1608
           const float ex = w.u - cm.x, ey = w.v - cm.y;
