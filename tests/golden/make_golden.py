@@ -33,6 +33,15 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes())
 
 
+def bow_nodes(desc, nodes=128):
+    """Stand-in for DBoW2's FeatureVector (the vocabulary file is not part of the reference mount): node id = hash of descriptor bits."""
+    ids = (desc[:, 0].astype(np.int64) >> 2) * 2 + (desc[:, 7].astype(np.int64) >> 7)
+    fv = {}
+    for i, n in enumerate(ids % nodes):
+        fv.setdefault(int(n) * 7 + 3, []).append(i)
+    return fv
+
+
 def main():
     for name, seed, H, W, nf in CASES:
         img = synth.make_frame(seed, H, W)
@@ -71,6 +80,28 @@ def main():
                         n_stress=n_st, moq_stress=moq_st, bd_stress=bd_st, slot_stress=F2.slot,
                         kps0_crc=crc(k0), kps1_crc=crc(k1))
     print("match: m2", n_m2, "stress", n_st)
+    # wider rows on the same pair: SearchForInitialization, SearchByBoW x2, ComputeDistinctiveDescriptors,
+    # and ComputeStereoMatches on a 20-px stereo pair
+    prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32).copy()
+    n_init, m12_init = O.search_for_initialization(k0, d0, O.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf), prev, 100, 0.9, True)
+    sigma2 = (sf * sf).astype(np.float32)
+    mp0 = (np.arange(len(k0)) % 5 != 0).astype(np.uint8)
+    mp1 = (np.arange(len(k1)) % 4 != 0).astype(np.uint8)
+    fv0, fv1 = bow_nodes(d0), bow_nodes(d1)
+    K0 = O.OracleKeyFrame(k0, d0, fv0, sf, sigma2, has_mp=mp0)
+    K1 = O.OracleKeyFrame(k1, d1, fv1, sf, sigma2, has_mp=mp1)
+    n_bow, m_bow = O.search_by_bow(K0, K1, 0.7, True)
+    n_bowkk, m_bowkk = O.search_by_bow_keyframes(K0, K1, 0.8, True)
+    groups = [d0[i:i + 3 + (i % 9)] for i in range(0, 400, 13)]
+    best = np.array([O.distinctive_descriptor(g) for g in groups], np.int32)
+    big = synth.make_frame(4120, H=480, W=752 + 64)
+    imgL, imgR = np.ascontiguousarray(big[:, 0:752]), np.ascontiguousarray(big[:, 20:20 + 752])
+    _, kL, dL = e.extract(imgL, (0, 0))
+    _, kR, dR = e.extract(imgR, (0, 0))
+    uR, depth = e.compute_stereo_matches(imgL, imgR, kL, dL, kR, dR, 0.11, 47.9)
+    np.savez_compressed(os.path.join(OUT, "wider_3000.npz"), n_init=n_init, m12_init=m12_init, prev_crc=crc(prev), n_bow=n_bow, m_bow=m_bow,
+                        n_bowkk=n_bowkk, m_bowkk=m_bowkk, best=best, uR=uR, depth=depth, kL_crc=crc(kL), kR_crc=crc(kR))
+    print("wider: init", n_init, "bow", n_bow, n_bowkk, "stereo", int((uR >= 0).sum()))
 
 
 if __name__ == "__main__":

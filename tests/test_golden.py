@@ -88,3 +88,73 @@ def test_hip_reproduces_match_golden(pkg, synth):
     assert n == int(g["n_stress"]) and np.array_equal(moq, g["moq_stress"]) and np.array_equal(bd, g["bd_stress"])
     assert np.array_equal(F2.slot, g["slot_stress"])
     e.close(); m.close()
+
+
+def _wider_inputs(synth, extract):
+    """Inputs of wider_3000.npz re-made from the seeds; `extract(img, lap)` -> (mono, kps, desc)."""
+    from golden.make_golden import bow_nodes
+    frames, offs = synth.make_stream(3000, 2)
+    _, k0, d0 = extract(frames[0], (0, 1000))
+    _, k1, d1 = extract(frames[1], (0, 1000))
+    big = synth.make_frame(4120, H=480, W=752 + 64)
+    imgL, imgR = np.ascontiguousarray(big[:, 0:752]), np.ascontiguousarray(big[:, 20:20 + 752])
+    mp0 = (np.arange(len(k0)) % 5 != 0).astype(np.uint8)
+    mp1 = (np.arange(len(k1)) % 4 != 0).astype(np.uint8)
+    groups = [d0[i:i + 3 + (i % 9)] for i in range(0, 400, 13)]
+    return k0, d0, k1, d1, bow_nodes(d0), bow_nodes(d1), mp0, mp1, groups, imgL, imgR
+
+
+def test_oracle_reproduces_wider_golden(oracle, synth):
+    g = load("wider_3000")
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    k0, d0, k1, d1, fv0, fv1, mp0, mp1, groups, imgL, imgR = _wider_inputs(synth, lambda im, lap: e.extract(im, lap))
+    sf = e.scale_factors
+    sigma2 = (sf * sf).astype(np.float32)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32).copy()
+    n, m12 = oracle.search_for_initialization(k0, d0, oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf), prev, 100, 0.9, True)
+    assert n == int(g["n_init"]) and np.array_equal(m12, g["m12_init"]) and crc(prev) == int(g["prev_crc"])
+    K0 = oracle.OracleKeyFrame(k0, d0, fv0, sf, sigma2, has_mp=mp0)
+    K1 = oracle.OracleKeyFrame(k1, d1, fv1, sf, sigma2, has_mp=mp1)
+    n, m = oracle.search_by_bow(K0, K1, 0.7, True)
+    assert n == int(g["n_bow"]) and np.array_equal(m, g["m_bow"])
+    n, m = oracle.search_by_bow_keyframes(K0, K1, 0.8, True)
+    assert n == int(g["n_bowkk"]) and np.array_equal(m, g["m_bowkk"])
+    assert np.array_equal(np.array([oracle.distinctive_descriptor(x) for x in groups], np.int32), g["best"])
+    _, kL, dL = e.extract(imgL, (0, 0))
+    _, kR, dR = e.extract(imgR, (0, 0))
+    assert crc(kL) == int(g["kL_crc"]) and crc(kR) == int(g["kR_crc"])
+    uR, depth = e.compute_stereo_matches(imgL, imgR, kL, dL, kR, dR, 0.11, 47.9)
+    assert np.array_equal(uR.view(np.uint32), g["uR"].view(np.uint32)) and np.array_equal(depth.view(np.uint32), g["depth"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_wider_golden(pkg, synth):
+    """The wider rows through the C ABI against the frozen fixture - no oracle in the loop."""
+    g = load("wider_3000")
+    ex, exR = pkg.ORBextractor(1000, 1.2, 8, 20, 7), pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    k0, d0, k1, d1, fv0, fv1, mp0, mp1, groups, imgL, imgR = _wider_inputs(synth, lambda im, lap: ex(im, None, lap))
+    sf = ex.GetScaleFactors()
+    sigma2 = (sf * sf).astype(np.float32)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    m9, m7, m8 = pkg.ORBmatcher(0.9, True), pkg.ORBmatcher(0.7, True), pkg.ORBmatcher(0.8, True)
+    try:
+        prev = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32).copy()
+        n, m12 = m9.SearchForInitialization(pkg.FrameView(k0, d0, bounds), pkg.FrameView(k1, d1, bounds), prev, 100)
+        assert n == int(g["n_init"]) and np.array_equal(m12, g["m12_init"]) and crc(prev) == int(g["prev_crc"])
+        K0 = pkg.KeyFrameView(k0, d0, fv0, sf, sigma2, has_mappoint=mp0)
+        K1 = pkg.KeyFrameView(k1, d1, fv1, sf, sigma2, has_mappoint=mp1)
+        n, m = m7.SearchByBoW(K0, K1)
+        assert n == int(g["n_bow"]) and np.array_equal(m, g["m_bow"])
+        n, m = m8.SearchByBoWKeyFrames(K0, K1)
+        assert n == int(g["n_bowkk"]) and np.array_equal(m, g["m_bowkk"])
+        assert np.array_equal(m8.ComputeDistinctiveDescriptors(groups), g["best"])
+        _, kL, dL = ex(imgL, None, (0, 0))
+        _, kR, dR = exR(imgR, None, (0, 0))
+        assert crc(kL) == int(g["kL_crc"]) and crc(kR) == int(g["kR_crc"])
+        uR, depth = ex.ComputeStereoMatches(exR, kL, dL, kR, dR, 0.11, 47.9)
+        assert np.array_equal(uR.view(np.uint32), g["uR"].view(np.uint32)) and np.array_equal(depth.view(np.uint32), g["depth"].view(np.uint32))
+    finally:
+        for x in (m9, m7, m8, ex, exR):
+            x.close()
+
