@@ -205,17 +205,15 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
       uint32_t packed = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int dx = dx0 + j;
-        if (dx < G.w) {
-          const int2 xt = sX[dx];
-          const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
-          const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
-          const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-          const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-          int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-          v = min(max(v, 0), 255);
-          packed |= (uint32_t)v << (8 * j);
-        }
+        const int dx = min(dx0 + j, G.w - 1);   // columns past the row end recompute the last one; only [0, w) is stored
+        const int2 xt = sX[dx];
+        const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+        const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        packed |= (uint32_t)v << (8 * j);
       }
       uint8_t *dst = dstplane + (size_t)dy * G.pitch;
       if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
