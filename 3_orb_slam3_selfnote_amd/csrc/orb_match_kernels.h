@@ -37,23 +37,6 @@ struct MatchProblemSet {
   long long *dbg;  // diagnostic builds (-DRESOLVE_STAMPS) only: per-problem cycle sums; never read by the product
 };
 
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl_xor(lo, o, 64);
-  hi = __shfl_xor(hi, o, 64);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// merge two (best <= second) pairs
-__device__ __forceinline__ void merge2(unsigned long long &b, unsigned long long &s, unsigned long long ob,
-                                       unsigned long long os) {
-  unsigned long long nb = b < ob ? b : ob;
-  unsigned long long mx = b < ob ? ob : b;
-  unsigned long long ms = s < os ? s : os;
-  s = mx < ms ? mx : ms;
-  b = nb;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Projection search = two kernels.
 //
@@ -83,7 +66,6 @@ struct Key32 {
   static __device__ __forceinline__ T make(int dist, uint32_t cell, int idx) { return ((uint32_t)dist << 23) | (cell << 11) | (uint32_t)idx; }
   static __device__ __forceinline__ int dist(T k) { return (int)(k >> 23); }
   static __device__ __forceinline__ int idx(T k) { return (int)(k & 0x7ffu); }
-  static __device__ __forceinline__ T shfl_xor(T v, int o) { return __shfl_xor(v, o, 64); }
   static __device__ __forceinline__ T readlane(T v, int l) { return (T)__builtin_amdgcn_readlane((int)v, l); }
 };
 struct Key64 {
@@ -92,7 +74,6 @@ struct Key64 {
   static __device__ __forceinline__ T make(int dist, uint32_t cell, int idx) { return ((T)dist << 40) | ((T)cell << 28) | ((T)idx << 8); }
   static __device__ __forceinline__ int dist(T k) { return (int)(k >> 40); }
   static __device__ __forceinline__ int idx(T k) { return (int)((k >> 8) & 0xfffff); }
-  static __device__ __forceinline__ T shfl_xor(T v, int o) { return shfl_xor_u64(v, o); }
   static __device__ __forceinline__ T readlane(T v, int l) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
     return ((T)hi << 32) | lo;
@@ -881,8 +862,7 @@ __global__ __launch_bounds__(256) void k_triangulation_match(TriParams T) {
       best = key < best ? key : best;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
+  best = wave_min_key(best);
   if (lane == 0) T.matches12[idx1] = best != 0xffffffffu ? T.node_idx2[item.start2 + (0xffff - (int)(best & 0xffff))] : -1;
 }
 
