@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
-    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches",
+    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
@@ -100,6 +100,8 @@ def load(build_if_needed=True):
     L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
     L.orbx_calibration_copy.argtypes = [vp, vp, sz, vp]
     L.orbx_compute_stereo_matches.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp]
+    L.orbx_cvt_color_gray.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, sz]
+    L.orbx_cvt_color_gray_device.argtypes = [vp, i32, i32, sz, i32, i32, vp, sz, vp]
     L.orbx_ref_cosf.restype = f32
     L.orbx_ref_cosf.argtypes = [f32]
     L.orbx_ref_sinf.restype = f32
@@ -244,6 +246,18 @@ class ORBextractor:
             raise OrbError("keypoint capacity bound violated: %d > %d" % (n.value, cap))
         self._check(rc, "orbx_extract")
         return rc, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def cvtColorGray(self, im, rgb=True):
+        """cvtColor(im, gray, CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) of Tracking::GrabImage* (Tracking.cc:1122-1135)."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        if im.ndim != 3 or im.shape[2] not in (3, 4):
+            raise ValueError("expected an H x W x 3|4 uint8 image")
+        H, W, ch = im.shape
+        out = np.empty((H, W), np.uint8)
+        rc = self.L.orbx_cvt_color_gray(self.h, _p(im), H, W, C.c_size_t(W * ch), ch, int(bool(rgb)), _p(out), C.c_size_t(W))
+        if rc < 0:
+            raise OrbError("orbx_cvt_color_gray rc=%d: %s" % (rc, self.L.orbx_last_error(self.h).decode()))
+        return out
 
     def ComputeStereoMatches(self, right, keysL, descL, keysR, descR, mb, mbf, frame_l=0, frame_r=0):
         """Frame::ComputeStereoMatches (Frame.cc:901-1079).  self / right = mpORBextractorLeft / Right after extracting the two

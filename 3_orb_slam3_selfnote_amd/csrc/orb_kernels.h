@@ -1008,6 +1008,27 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   }
 }
 
+// cv::cvtColor(im, gray, CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) as called by Tracking::GrabImage*
+// (Tracking.cc:1122-1135) for 8-bit images: OpenCV's fixed-point RGB2Gray, (R*4899 + G*9617 + B*1868 + 8192) >> 14
+// (R2Y, G2Y, B2Y with yuv_shift 14; alpha ignored).  Four output pixels per thread, dword store.
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t *src, int rows, int cols, size_t sstride, int ch, int rgb, uint8_t *dst,
+                                                  size_t dstride) {
+  const int q = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const int x0 = 4 * q;
+  if (x0 >= cols || y >= rows) return;
+  const uint8_t *s = src + (size_t)y * sstride + (size_t)x0 * ch;
+  const int cr = rgb ? 0 : 2, cb = rgb ? 2 : 0;
+  uint32_t packed = 0;
+  const int n = min(4, cols - x0);
+  for (int j = 0; j < n; j++) {
+    const uint32_t g = ((uint32_t)s[j * ch + cr] * 4899u + (uint32_t)s[j * ch + 1] * 9617u + (uint32_t)s[j * ch + cb] * 1868u + 8192u) >> 14;
+    packed |= g << (8 * j);
+  }
+  uint8_t *d = dst + (size_t)y * dstride + x0;
+  if (n == 4 && ((((uintptr_t)dst) | dstride) & 3u) == 0) *reinterpret_cast<uint32_t *>(d) = packed;
+  else for (int j = 0; j < n; j++) d[j] = (uint8_t)(packed >> (8 * j));
+}
+
 // per-frame {n, monoIndex} (ORBextractor.cc:1183 returns monoIndex)
 __global__ void k_counts(FrameParams P) {
   const int frame = blockIdx.x * blockDim.x + threadIdx.x;

@@ -617,6 +617,31 @@ int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *s
   return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
 }
 
+int orbx_cvt_color_gray_device(const uint8_t *d_src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *d_dst,
+                               size_t dst_stride, void *stream) {
+  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || (channels != 3 && channels != 4) || src_stride < (size_t)cols * channels || dst_stride < (size_t)cols)
+    return ORBX_E_ARG;
+  hipLaunchKernelGGL(k_cvt_gray, dim3((cols + 1023) / 1024, rows), dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, src_stride, channels,
+                     rgb_order ? 1 : 0, d_dst, dst_stride);
+  return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
+}
+
+int orbx_cvt_color_gray(orbx_t *h, const uint8_t *src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *dst,
+                        size_t dst_stride) {
+  if (!h || !src || !dst || rows <= 0 || cols <= 0 || (channels != 3 && channels != 4) || src_stride < (size_t)cols * channels || dst_stride < (size_t)cols)
+    return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  const size_t sbytes = (size_t)cols * channels, dpitch = align_up((size_t)cols, 64);
+  XCHECK(h, h->stereo[0].reserve(sbytes * rows));
+  XCHECK(h, h->stereo[1].reserve(dpitch * rows));
+  XCHECK(h, hipMemcpy2DAsync(h->stereo[0].p, sbytes, src, src_stride, sbytes, (size_t)rows, hipMemcpyHostToDevice, h->stream));
+  const int rc = orbx_cvt_color_gray_device((const uint8_t *)h->stereo[0].p, rows, cols, sbytes, channels, rgb_order, (uint8_t *)h->stereo[1].p, dpitch, h->stream);
+  if (rc < 0) return rc;
+  XCHECK(h, hipMemcpy2DAsync(dst, dst_stride, h->stereo[1].p, dpitch, (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int orbx_level_info(const orbx_t *h, int level, int *rows, int *cols) {
   if (!h || level < 0 || level >= h->nlevels || h->geom.empty()) return ORBX_E_ARG;
   if (rows) *rows = h->geom[level].h;

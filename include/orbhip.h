@@ -111,6 +111,14 @@ int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *s
 float orbx_ref_cosf(float x);
 float orbx_ref_sinf(float x);
 
+/* cv::cvtColor(im, gray, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY) of Tracking::GrabImageMonocular / Stereo / RGBD
+ * (Tracking.cc:1122-1135) for 8-bit input: channels = 3 or 4, rgb_order != 0 for RGB(A), 0 for BGR(A).
+ * Fixed point as in OpenCV 3.x: (R*4899 + G*9617 + B*1868 + 8192) >> 14.  *_device: device pointers, asynchronous on stream. */
+int orbx_cvt_color_gray_device(const uint8_t *d_src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *d_dst,
+                               size_t dst_stride, void *stream);
+int orbx_cvt_color_gray(orbx_t *h, const uint8_t *src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *dst,
+                        size_t dst_stride);
+
 /* void Frame::ComputeStereoMatches()  (Frame.cc:901-1079), rectified stereo - the consumer of mvImagePyramid.
  * left / right: the two extractors (mpORBextractorLeft / Right) AFTER orbx_extract / orbx_extract_batch_device of the
  * two images: their pyramids are still on the device (frame_l / frame_r = index in their last batch), so no image

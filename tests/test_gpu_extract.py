@@ -269,3 +269,17 @@ def test_compute_stereo_matches_edge_cases(pkg, synth):
         assert (uR == -1).all() and (depth == -1).all()
     finally:
         exL.close(); exR.close()
+
+
+@pytest.mark.parametrize("ch,rgb", [(3, True), (3, False), (4, True), (4, False)])
+def test_cvt_color_gray(pkg, ex, ch, rgb):
+    """cvtColor to gray as Tracking::GrabImage* applies it (Tracking.cc:1122-1135): OpenCV's fixed-point weights, checked
+    against the same integer formula in numpy (incl. a width that is not a multiple of 4)."""
+    rng = np.random.default_rng(ch * 2 + rgb)
+    for (H, W) in [(480, 752), (37, 101)]:
+        im = rng.integers(0, 256, (H, W, ch), dtype=np.uint8)
+        r, g, b = (im[..., 0], im[..., 1], im[..., 2]) if rgb else (im[..., 2], im[..., 1], im[..., 0])
+        ref = ((r.astype(np.uint32) * 4899 + g.astype(np.uint32) * 9617 + b.astype(np.uint32) * 1868 + 8192) >> 14).astype(np.uint8)
+        assert np.array_equal(ex.cvtColorGray(im, rgb), ref)
+    white = np.full((8, 8, ch), 255, np.uint8)
+    assert (ex.cvtColorGray(white, rgb) == 255).all()
