@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -125,6 +125,7 @@ def load(build_if_needed=True):
     L.orbm_distinctive_descriptors.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_knn_match2.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, f32, i32, vp]
+    L.orbm_search_by_bow_fisheye.argtypes = [vp, vp, vp, i32, f32, i32, vp]
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
@@ -551,12 +552,15 @@ class ORBmatcher:
             raise OrbError("orbm_search_for_initialization rc=%d" % rc)
         return rc, m12
 
-    def SearchByBoW(self, KF, F):
+    def SearchByBoW(self, KF, F, n_left=None):
         """SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) -- ORBmatcher.cc:273-469 (Nleft == -1).
         KF, F: KeyFrameView (KF.has_mappoint = pMP && !isBad).  Returns (nmatches, matchF[F.N] = keyframe keypoint index or -1)."""
         m = np.full(max(F.N, 1), -1, dtype=np.int32)
         ks, fs = KF.struct(), F.struct()
-        rc = self.L.orbm_search_by_bow(self.m, C.byref(ks), C.byref(fs), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m))
+        if n_left is not None:   # fisheye-stereo frame: F = mvKeys ++ mvKeysRight, Frame::Nleft = n_left
+            rc = self.L.orbm_search_by_bow_fisheye(self.m, C.byref(ks), C.byref(fs), int(n_left), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m))
+        else:
+            rc = self.L.orbm_search_by_bow(self.m, C.byref(ks), C.byref(fs), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m))
         self._check(rc, "orbm_search_by_bow")
         if rc < 0:
             raise OrbError("orbm_search_by_bow rc=%d" % rc)

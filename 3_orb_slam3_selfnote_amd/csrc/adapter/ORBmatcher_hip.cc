@@ -275,7 +275,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
 }
 
 int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
-  if (F.Nleft != -1 || pKF->mpCamera2) return SearchByBoW_ref(pKF, F, vpMapPointMatches);  // two-camera rigs: reference path
+  // Two-camera (fisheye) rigs: keypoint k of a view is mvKeys[k] for k < Nleft and mvKeysRight[k - Nleft] after it (:383-395);
+  // the C ABI takes that concatenation.  A rig on one side only would mix mvKeysUn with raw keys: reference path.
+  if ((F.Nleft != -1) != (pKF->mpCamera2 != nullptr)) return SearchByBoW_ref(pKF, F, vpMapPointMatches);
   const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
   vpMapPointMatches.assign(F.N, static_cast<MapPoint *>(NULL));  // :277
   struct Flat { std::vector<uint8_t> has; std::vector<uint32_t> id; std::vector<int32_t> start, idx; orbm_keyframe_t k; };
@@ -295,13 +297,20 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
   flatten(F.mFeatVec, B);
   A.has.resize(pKF->N);
   for (int i = 0; i < pKF->N; i++) A.has[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();  // :307-313
-  A.k.n = pKF->N; A.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(pKF->mvKeysUn.data());
+  std::vector<cv::KeyPoint> keysKF, keysF;
+  const bool rig = F.Nleft != -1;
+  if (rig) {
+    keysKF = pKF->mvKeys; keysKF.insert(keysKF.end(), pKF->mvKeysRight.begin(), pKF->mvKeysRight.end());
+    keysF = F.mvKeys; keysF.insert(keysF.end(), F.mvKeysRight.begin(), F.mvKeysRight.end());
+  }
+  A.k.n = pKF->N; A.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(rig ? keysKF.data() : pKF->mvKeysUn.data());
   A.k.descriptors = pKF->mDescriptors.data; A.k.has_mappoint = A.has.data();
   B.has.assign(F.N, 0);
-  B.k.n = F.N; B.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(F.mvKeys.data());  // angle of F.mvKeys, :395
+  B.k.n = F.N; B.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(rig ? keysF.data() : F.mvKeys.data());  // angle of F.mvKeys, :395
   B.k.descriptors = F.mDescriptors.data; B.k.has_mappoint = B.has.data();
   std::vector<int32_t> mF(F.N, -1);
-  const int n = orbm_search_by_bow(matcher(), &A.k, &B.k, mfNNratio, mbCheckOrientation ? 1 : 0, mF.data());
+  const int n = rig ? orbm_search_by_bow_fisheye(matcher(), &A.k, &B.k, F.Nleft, mfNNratio, mbCheckOrientation ? 1 : 0, mF.data())
+                    : orbm_search_by_bow(matcher(), &A.k, &B.k, mfNNratio, mbCheckOrientation ? 1 : 0, mF.data());
   if (n < 0) throw std::runtime_error(orbm_last_error(matcher()));
   for (int i = 0; i < F.N; i++)
     if (mF[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[mF[i]];  // :389

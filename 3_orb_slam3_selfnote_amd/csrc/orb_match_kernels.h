@@ -884,6 +884,9 @@ struct BowParams {
   // keyframe's keypoints that may be taken (:896-903), strict = accept needs bestDist1 < TH_LOW (:923, not <=),
   // match12[KF.N] = taken keypoint of the second keyframe per keypoint of the first (:927); all 0 / NULL otherwise
   const uint8_t *hasmpF; int strict; int32_t *match12;
+  // fisheye-stereo frame (Frame::Nleft != -1, :338-363, :405-436): frame keypoints >= nleftF belong to the right image and
+  // are matched separately (accepted whenever the LEFT best is within TH_LOW, `|| true` at :407); 0x7fffffff otherwise
+  int nleftF;
 };
 
 __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
@@ -899,7 +902,8 @@ __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
     uint32_t dk[8];
 #pragma unroll
     for (int w = 0; w < 8; w++) dk[w] = B.descKF[(size_t)idxKF * 8 + w];
-    uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
+    const bool stereoF = B.nleftF != 0x7fffffff;
+    uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu, r1 = 0xffffffffu;
     for (int t = 0; t < nt; t++) {
       const int pos = lane + 64 * t;
       if (pos < item.lenF && !((taken >> t) & 1u)) {                 // :321
@@ -909,20 +913,35 @@ __global__ __launch_bounds__(256) void k_bow_match(BowParams B) {
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(dk[w] ^ B.descF[(size_t)idxF * 8 + w]);
         const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)pos;
-        if (key < b1) { b2 = b1; b1 = key; }
-        else if (key < b2) b2 = key;
+        if (idxF < B.nleftF) {                                         // :326-335 resp. :347-354
+          if (key < b1) { b2 = b1; b1 = key; }
+          else if (key < b2) b2 = key;
+        } else {
+          r1 = key < r1 ? key : r1;                                    // :356-363 (the right second-best is never used, :407)
+        }
       }
     }
     const uint32_t g1 = wave_min_key(b1);
     const uint32_t g2 = wave_min_key(b1 == g1 ? b2 : b1);
     const int bestDist1 = g1 != 0xffffffffu ? (int)(g1 >> 16) : 256, bestDist2 = g2 != 0xffffffffu ? (int)(g2 >> 16) : 256;
-    if ((B.strict ? bestDist1 < ORBM_TH_LOW : bestDist1 <= ORBM_TH_LOW) && (float)bestDist1 < B.nnratio * (float)bestDist2) {   // :385-387
+    const bool within = B.strict ? bestDist1 < ORBM_TH_LOW : bestDist1 <= ORBM_TH_LOW;
+    if (within && (float)bestDist1 < B.nnratio * (float)bestDist2) {   // :385-387
       const int pos = (int)(g1 & 0xffffu);
       if (lane == (pos & 63)) {
         taken |= 1u << (pos >> 6);
         const int idxF = B.node_idxF[item.startF + pos];
         if (B.matchF) B.matchF[idxF] = idxKF;                          // :389
         if (B.match12) B.match12[idxKF] = idxF;                        // :927
+      }
+    }
+    if (stereoF && within) {                                           // :405-436, inside `if(bestDist1<=TH_LOW)`
+      const uint32_t gr = wave_min_key(r1);
+      if (gr != 0xffffffffu && (int)(gr >> 16) <= ORBM_TH_LOW) {
+        const int pos = (int)(gr & 0xffffu);
+        if (lane == (pos & 63)) {
+          taken |= 1u << (pos >> 6);
+          if (B.matchF) B.matchF[B.node_idxF[item.startF + pos]] = idxKF;   // :409
+        }
       }
     }
   }

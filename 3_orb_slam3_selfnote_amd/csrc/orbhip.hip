@@ -1813,7 +1813,7 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
 
 // Shared by the two SearchByBoW overloads.  kf_kf: second operand is a keyframe (candidates need a good map point, strict
 // threshold, result indexed by the first keyframe's keypoints: out[kf->n]); otherwise out[f->n] is indexed by frame keypoint.
-static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, bool kf_kf, int32_t *out) {
+static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, bool kf_kf, int nleftF, int32_t *out) {
   if (!m || !kf || !f || !out || kf->n < 0 || f->n < 0) return ORBX_E_ARG;
   const int nout = kf_kf ? kf->n : f->n;
   for (int i = 0; i < nout; i++) out[i] = -1;                     // :277 / :852
@@ -1853,6 +1853,7 @@ static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t 
   B.node_idxKF = (const int32_t *)bufs[3].p; B.node_idxF = (const int32_t *)bufs[4].p;
   B.items = (const BowItem *)bufs[5].p; B.nitems = (int)items.size();
   B.nnratio = nnratio;
+  B.nleftF = nleftF >= 0 ? nleftF : 0x7fffffff;
   if (kf_kf) { B.match12 = (int32_t *)bufs[6].p; B.hasmpF = (const uint8_t *)bufs[7].p; B.strict = 1; }
   else B.matchF = (int32_t *)bufs[6].p;
   hipLaunchKernelGGL(k_bow_match, dim3((B.nitems + 3) / 4), dim3(256), 0, s, B);
@@ -1885,12 +1886,18 @@ static int bow_core(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t 
 }
 
 int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF) {
-  return bow_core(m, kf, f, nnratio, checkOri, false, matchF);
+  return bow_core(m, kf, f, nnratio, checkOri, false, -1, matchF);
+}
+
+int orbm_search_by_bow_fisheye(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, int n_left_f, float nnratio, int checkOri,
+                               int32_t *matchF) {
+  if (n_left_f < 0 || (f && n_left_f > f->n)) return ORBX_E_ARG;
+  return bow_core(m, kf, f, nnratio, checkOri, false, n_left_f, matchF);
 }
 
 int orbm_search_by_bow_keyframes(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float nnratio, int checkOri,
                                  int32_t *matches12) {
-  return bow_core(m, kf1, kf2, nnratio, checkOri, true, matches12);
+  return bow_core(m, kf1, kf2, nnratio, checkOri, true, -1, matches12);
 }
 
 int orbm_distinctive_descriptors(orbm_t *m, int nmp, const int32_t *start, const uint8_t *desc, int32_t *best) {

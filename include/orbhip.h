@@ -345,6 +345,13 @@ int orbm_search_for_initialization(orbm_t *m, const orbm_frame_t *f1, const orbm
  * vocabulary node on the device; rotation histogram on the host.  Returns nmatches. */
 int orbm_search_by_bow(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, float nnratio, int checkOri, int32_t *matchF);
 
+/* The same member for a fisheye-stereo frame (Frame::Nleft != -1, ORBmatcher.cc:338-363, :405-436): f holds mvKeys followed by
+ * mvKeysRight / the concatenated mDescriptors, keypoints >= n_left_f are the right image's; kf->keys_un likewise carries the
+ * keypoint the reference picks for the angle (:391-394).  A keyframe keypoint can hand its map point to one left AND one right
+ * frame keypoint; matchF marks both. */
+int orbm_search_by_bow_fisheye(orbm_t *m, const orbm_keyframe_t *kf, const orbm_keyframe_t *f, int n_left_f, float nnratio, int checkOri,
+                               int32_t *matchF);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)    (ORBmatcher.cc:839-979)
  * has_mappoint[i] = pMP && !pMP->isBad() on both sides; matches12[kf1->n] (out) = keypoint of kf2 whose map point
  * keypoint i of kf1 was matched with (vpMatches12[i] = vpMapPoints2[matches12[i]]) or -1.  Returns nmatches. */

@@ -384,12 +384,12 @@ def search_for_triangulation(K1, K2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, only_s
     return n, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
 
 
-def search_by_bow(KF, F, nnratio=0.7, check_ori=True):
-    """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:273-469) on two OracleKeyFrame views."""
+def search_by_bow(KF, F, nnratio=0.7, check_ori=True, n_left=-1):
+    """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:273-469) on two OracleKeyFrame views; n_left = F.Nleft."""
     L = lib()
-    L.orc_search_by_bow_kf_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    L.orc_search_by_bow_kf_frame_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
     m = np.full(max(F.N, 1), -1, dtype=np.int32)
-    n = L.orc_search_by_bow_kf_frame(C.byref(KF.k), C.byref(F.k), C.c_float(nnratio), int(check_ori), _p(m))
+    n = L.orc_search_by_bow_kf_frame_stereo(C.byref(KF.k), C.byref(F.k), int(n_left), C.c_float(nnratio), int(check_ori), _p(m))
     return n, m[:F.N]
 
 

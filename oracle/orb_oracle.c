@@ -1811,13 +1811,20 @@ void orc_image_bounds(int cols, int rows, const float *K, const float *D, int nD
 /* ORBmatcher.cc:273-469, Frame::Nleft == -1.  Both sides as orc_keyframe (the frame's has_mp    */
 /* is unused); matchF[F.N] = keyframe keypoint index whose map point the frame keypoint got.    */
 /* ------------------------------------------------------------------------------------------ */
+int orc_search_by_bow_kf_frame_stereo(const orc_keyframe *KF, const orc_keyframe *F, int Nleft, float nnratio, int checkOri, int32_t *matchF);
 int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF) {
+  return orc_search_by_bow_kf_frame_stereo(KF, F, -1, nnratio, checkOri, matchF);
+}
+
+/* Nleft = F.Nleft (-1: mono / rectified frame).  For Nleft != -1 F holds mvKeys ++ mvKeysRight and the branch :338-363 /
+ * :405-436 applies: separate best for the right image, accepted inside `if(bestDist1<=TH_LOW)` with `|| true` (:407). */
+int orc_search_by_bow_kf_frame_stereo(const orc_keyframe *KF, const orc_keyframe *F, int Nleft, float nnratio, int checkOri, int32_t *matchF) {
   const int HISTO_LENGTH = 30, TH_LOW = 50;
   int nmatches = 0;
   for (int i = 0; i < F->N; i++) matchF[i] = -1;
   int *rotHist[30];
   int rotN[30];
-  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(F->N + 1)); rotN[i] = 0; }
+  for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(2 * F->N + 1)); rotN[i] = 0; }
   const float factor = 1.0f / HISTO_LENGTH;
   int a = 0, b = 0;
   while (a < KF->n_nodes && b < F->n_nodes) {
@@ -1827,12 +1834,20 @@ int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, fl
         if (!KF->has_mp[realIdxKF]) continue;
         const uint8_t *dKF = KF->desc + 32 * (size_t)realIdxKF;
         int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
         for (int iF = F->node_start[b]; iF < F->node_start[b + 1]; iF++) {
           const int realIdxF = F->node_idx[iF];
           if (matchF[realIdxF] >= 0) continue;
           const int dist = orc_descriptor_distance(dKF, F->desc + 32 * (size_t)realIdxF);
-          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
-          else if (dist < bestDist2) bestDist2 = dist;
+          if (Nleft == -1) {
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (dist < bestDist2) bestDist2 = dist;
+          } else {
+            if (realIdxF < Nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (realIdxF < Nleft && dist < bestDist2) bestDist2 = dist;
+            if (realIdxF >= Nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+            else if (realIdxF >= Nleft && dist < bestDist2R) bestDist2R = dist;
+          }
         }
         if (bestDist1 <= TH_LOW) {
           if ((float)bestDist1 < nnratio * (float)bestDist2) {
@@ -1845,6 +1860,19 @@ int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, fl
               rotHist[bin][rotN[bin]++] = bestIdxF;
             }
             nmatches++;
+          }
+          if (bestDist1R <= TH_LOW) {
+            if ((float)bestDist1R < nnratio * (float)bestDist2R || 1) {
+              matchF[bestIdxFR] = realIdxKF;
+              if (checkOri) {
+                float rot = KF->angle[realIdxKF] - F->angle[bestIdxFR];
+                if ((double)rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin][rotN[bin]++] = bestIdxFR;
+              }
+              nmatches++;
+            }
           }
         }
       }

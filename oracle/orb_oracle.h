@@ -197,6 +197,7 @@ typedef struct {
 
 /* N3 (first member): SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), ORBmatcher.cc:273-469 (Nleft == -1). */
 int orc_search_by_bow_kf_frame(const orc_keyframe *KF, const orc_keyframe *F, float nnratio, int checkOri, int32_t *matchF);
+int orc_search_by_bow_kf_frame_stereo(const orc_keyframe *KF, const orc_keyframe *F, int Nleft, float nnratio, int checkOri, int32_t *matchF);
 /* N3: the search part of the two ORBmatcher::Fuse overloads, ORBmatcher.cc:1425-1658 and :1660-1786. */
 int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
              const float *maxDist, const float *minDist, const float *Tcw, const float *Ow, int camType, const float *cam, float bf,

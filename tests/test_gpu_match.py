@@ -606,3 +606,32 @@ def test_knn_match2(pkg, matcher, synth):
     assert np.array_equal(dist, np.take_along_axis(D, order, axis=1).astype(np.int32))
     i1, d1 = matcher.knnMatch2(q[:3], c[:1])
     assert (i1[:, 0] == 0).all() and (i1[:, 1] == -1).all() and (d1[:, 1] == -1).all()
+
+
+@pytest.mark.parametrize("nodes", [128, 16])
+def test_search_by_bow_fisheye_n3(pkg, oracle, synth, nodes):
+    """SearchByBoW(KeyFrame*, Frame&) with a fisheye-stereo frame (ORBmatcher.cc:338-363, :405-436): a keyframe keypoint takes the
+    best left-image keypoint under the ratio test and, whenever its left best is within TH_LOW, also the best right-image one."""
+    frames, offs = synth.make_stream(3880, 3)
+    o = oracle.OracleExtractor(**EUROC)
+    (_, k0, d0), (_, kl, dl), (_, kr, dr) = o.extract(frames[0]), o.extract(frames[1]), o.extract(frames[2])
+    sf = o.scale_factors
+    sigma2 = (sf * sf).astype(np.float32)
+    rng = np.random.default_rng(nodes + 7)
+    mp0 = (rng.random(len(k0)) < 0.85).astype(np.uint8)
+    kf_keys, kf_desc = k0, d0
+    f_keys, f_desc = np.concatenate([kl, kr]), np.concatenate([dl, dr])
+    fv0, fv1 = _bow(kf_desc, nodes), _bow(f_desc, nodes)
+    KF = pkg.KeyFrameView(kf_keys, kf_desc, fv0, sf, sigma2, has_mappoint=mp0)
+    F = pkg.KeyFrameView(f_keys, f_desc, fv1, sf, sigma2)
+    OKF = oracle.OracleKeyFrame(kf_keys, kf_desc, fv0, sf, sigma2, has_mp=mp0)
+    OF = oracle.OracleKeyFrame(f_keys, f_desc, fv1, sf, sigma2)
+    m = pkg.ORBmatcher(0.7, True)
+    try:
+        n_gpu, m_gpu = m.SearchByBoW(KF, F, n_left=len(kl))
+        n_ref, m_ref = oracle.search_by_bow(OKF, OF, 0.7, True, n_left=len(kl))
+        assert n_gpu == n_ref and n_ref > 150
+        assert np.array_equal(m_gpu, m_ref)
+        assert (m_ref[len(kl):] >= 0).sum() > 50 and (m_ref[:len(kl)] >= 0).sum() > 50     # both images receive matches
+    finally:
+        m.close()
