@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
+    "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
@@ -102,6 +103,10 @@ def load(build_if_needed=True):
     L.orbx_compute_stereo_matches.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp]
     L.orbx_cvt_color_gray.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, sz]
     L.orbx_cvt_color_gray_device.argtypes = [vp, i32, i32, sz, i32, i32, vp, sz, vp]
+    L.orbx_clahe.argtypes = [vp, vp, i32, i32, sz, C.c_double, i32, i32, vp, sz]
+    L.orbx_clahe_device.argtypes = [vp, i32, i32, sz, C.c_double, i32, i32, vp, vp, sz, vp]
+    L.orbx_remap_linear.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, i32, vp, sz]
+    L.orbx_remap_linear_device.argtypes = [vp, i32, i32, sz, vp, vp, sz, i32, i32, vp, sz, vp]
     L.orbx_ref_cosf.restype = f32
     L.orbx_ref_cosf.argtypes = [f32]
     L.orbx_ref_sinf.restype = f32
@@ -258,6 +263,35 @@ class ORBextractor:
         rc = self.L.orbx_cvt_color_gray(self.h, _p(im), H, W, C.c_size_t(W * ch), ch, int(bool(rgb)), _p(out), C.c_size_t(W))
         if rc < 0:
             raise OrbError("orbx_cvt_color_gray rc=%d: %s" % (rc, self.L.orbx_last_error(self.h).decode()))
+        return out
+
+    def CLAHE(self, im, clip_limit=3.0, tiles=(8, 8)):
+        """cv::createCLAHE(clip_limit, Size(tiles))->apply(im, im) of the TUM-VI examples (mono_tum_vi.cc:101-109)."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        if im.ndim != 2:
+            raise ValueError("expected an H x W uint8 image")
+        H, W = im.shape
+        out = np.empty((H, W), np.uint8)
+        rc = self.L.orbx_clahe(self.h, _p(im), H, W, C.c_size_t(W), C.c_double(clip_limit), int(tiles[0]), int(tiles[1]), _p(out), C.c_size_t(W))
+        if rc < 0:
+            raise OrbError("orbx_clahe rc=%d: %s" % (rc, self.L.orbx_last_error(self.h).decode()))
+        return out
+
+    def remap(self, im, mapx=None, mapy=None, size=None):
+        """cv::remap(im, out, M1, M2, INTER_LINEAR) of the stereo examples (stereo_euroc.cc:166-167).  Maps are kept on the device:
+        leave them out (and give size=(rows, cols)) to reuse the ones of the previous call."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        if mapx is not None:
+            mapx = np.ascontiguousarray(mapx, dtype=np.float32); mapy = np.ascontiguousarray(mapy, dtype=np.float32)
+            if mapx.shape != mapy.shape or mapx.ndim != 2:
+                raise ValueError("mapx / mapy must be equal-shaped 2-D float32 arrays")
+            size = mapx.shape
+        H, W = size
+        out = np.empty((H, W), np.uint8)
+        rc = self.L.orbx_remap_linear(self.h, _p(im), im.shape[0], im.shape[1], C.c_size_t(im.shape[1]), _p(mapx) if mapx is not None else None,
+                                      _p(mapy) if mapy is not None else None, H, W, _p(out), C.c_size_t(W))
+        if rc < 0:
+            raise OrbError("orbx_remap_linear rc=%d: %s" % (rc, self.L.orbx_last_error(self.h).decode()))
         return out
 
     def ComputeStereoMatches(self, right, keysL, descL, keysR, descR, mb, mbf, frame_l=0, frame_r=0):

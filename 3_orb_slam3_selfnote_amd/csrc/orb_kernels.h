@@ -1029,6 +1029,120 @@ __global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t *src, int rows, 
   else for (int j = 0; j < n; j++) d[j] = (uint8_t)(packed >> (8 * j));
 }
 
+// cv::CLAHE::apply as the TUM-VI examples run it on every image before TrackMonocular / TrackStereo
+// (Examples/Monocular/mono_tum_vi.cc:101-109, createCLAHE(3.0, Size(8, 8))), OpenCV 3.4/4.x clahe.cpp for CV_8UC1:
+// per-tile histogram -> clip at clipLimit, the excess spread evenly (batch + every residualStep-th bin) -> cumulative
+// LUT saturate_cast<uchar>(sum * lutScale); then every pixel blends the LUTs of its four neighbouring tiles bilinearly
+// in float.  When the image size is not a multiple of the tile grid the histogram runs over the image extended to the
+// next multiple with BORDER_REFLECT_101 (tw, th are the tile sizes of the extended image).
+// k_clahe_lut: one workgroup per tile, thread b owns histogram bin b.
+__global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *src, int rows, int cols, size_t sstride, int tilesX, int tw, int th, int clipLimit,
+                                                   float lutScale, uint8_t *lut) {
+  __shared__ uint32_t hist[256];
+  __shared__ int part[4];
+  const int t = threadIdx.x, tile = blockIdx.x, tx = tile % tilesX, ty = tile / tilesX;
+  hist[t] = 0;
+  __syncthreads();
+  const int x0 = tx * tw, y0 = ty * th;
+  for (int i = t; i < tw * th; i += 256) {
+    int y = y0 + i / tw, x = x0 + i % tw;
+    if (y >= rows) y = 2 * (rows - 1) - y;   // BORDER_REFLECT_101, the extension is narrower than the image
+    if (x >= cols) x = 2 * (cols - 1) - x;
+    atomicAdd(&hist[src[(size_t)y * sstride + x]], 1u);
+  }
+  __syncthreads();
+  int v = (int)hist[t];
+  if (clipLimit > 0) {
+    int excess = v > clipLimit ? v - clipLimit : 0;
+    if (v > clipLimit) v = clipLimit;
+    const int ws = wave_sum_i32(excess);
+    if ((t & 63) == 0) part[t >> 6] = ws;
+    __syncthreads();
+    const int clipped = part[0] + part[1] + part[2] + part[3];
+    const int redistBatch = clipped / 256;
+    const int residual = clipped - redistBatch * 256;
+    v += redistBatch;
+    if (residual != 0) {
+      const int step = max(256 / residual, 1);
+      if (t % step == 0 && t / step < residual) v++;
+    }
+  }
+  __syncthreads();
+  hist[t] = (uint32_t)v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {   // inclusive scan over the 256 bins
+    const uint32_t a = t >= d ? hist[t - d] : 0u;
+    __syncthreads();
+    hist[t] += a;
+    __syncthreads();
+  }
+  const int r = __float2int_rn(__fmul_rn((float)(int)hist[t], lutScale));
+  lut[(size_t)tile * 256 + t] = (uint8_t)min(max(r, 0), 255);
+}
+
+// k_clahe_interp: the whole LUT (tilesX*tilesY*256 bytes, 16 KB for 8x8) sits in LDS; four pixels per thread.
+// Every product and sum is rounded on its own, as the reference's scalar float expression is (no fused multiply-add).
+__global__ __launch_bounds__(256) void k_clahe_interp(const uint8_t *src, int rows, int cols, size_t sstride, int tilesX, int tilesY, float inv_tw,
+                                                      float inv_th, const uint8_t *lut, uint8_t *dst, size_t dstride, int rowsPerBlock) {
+  extern __shared__ uint8_t sLut[];
+  const int nl = tilesX * tilesY * 256;
+  for (int i = threadIdx.x * 4; i < nl; i += 1024) *reinterpret_cast<uint32_t *>(sLut + i) = *reinterpret_cast<const uint32_t *>(lut + i);
+  __syncthreads();
+  const int yb = blockIdx.x * rowsPerBlock, ye = min(yb + rowsPerBlock, rows);
+  const int nq = (cols + 3) >> 2;
+  for (int i = threadIdx.x; i < (ye - yb) * nq; i += 256) {
+    const int y = yb + i / nq, xq = (i % nq) * 4;
+    const float tyf = __fsub_rn(__fmul_rn((float)y, inv_th), 0.5f);
+    int ty1 = (int)floorf(tyf);
+    const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
+    const int ty2 = min(ty1 + 1, tilesY - 1);
+    ty1 = max(ty1, 0);
+    const uint8_t *p1 = sLut + ty1 * tilesX * 256, *p2 = sLut + ty2 * tilesX * 256;
+    const uint8_t *srow = src + (size_t)y * sstride;
+    uint8_t *drow = dst + (size_t)y * dstride;
+    const int n = min(4, cols - xq);
+    uint32_t packed = 0;
+    for (int j = 0; j < n; j++) {
+      const int x = xq + j;
+      const float txf = __fsub_rn(__fmul_rn((float)x, inv_tw), 0.5f);
+      int tx1 = (int)floorf(txf);
+      const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
+      const int tx2 = min(tx1 + 1, tilesX - 1);
+      tx1 = max(tx1, 0);
+      const int sv = srow[x];
+      const int i1 = tx1 * 256 + sv, i2 = tx2 * 256 + sv;
+      const float top = __fadd_rn(__fmul_rn((float)p1[i1], xa1), __fmul_rn((float)p1[i2], xa));
+      const float bot = __fadd_rn(__fmul_rn((float)p2[i1], xa1), __fmul_rn((float)p2[i2], xa));
+      const float res = __fadd_rn(__fmul_rn(top, ya1), __fmul_rn(bot, ya));
+      packed |= (uint32_t)min(max(__float2int_rn(res), 0), 255) << (8 * j);
+    }
+    if (n == 4 && ((((uintptr_t)dst) | dstride) & 3u) == 0) *reinterpret_cast<uint32_t *>(drow + xq) = packed;
+    else for (int j = 0; j < n; j++) drow[xq + j] = (uint8_t)(packed >> (8 * j));
+  }
+}
+
+// cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of the stereo examples (Examples/Stereo/stereo_euroc.cc:166-167), with the
+// CV_32FC1 maps initUndistortRectifyMap(..., CV_32F, M1, M2) produced (:113-114) and the default BORDER_CONSTANT (0).  OpenCV
+// quantises the source coordinate to 1/32 pixel (cvRound(map * INTER_TAB_SIZE)), takes the bilinear weights from a table of
+// 15-bit fixed-point products -- for the linear kernel exactly 32 * (32-fx|fx) * (32-fy|fy); the one saturated entry of the table
+// (fx = fy = 0: {32767, 0, 0, 1} after its correction step) yields the same pixel as {32768, 0, 0, 0} for 8-bit taps -- and rounds
+// with (sum + (1 << 14)) >> 15.  A tap outside the source contributes the border value.
+__global__ __launch_bounds__(256) void k_remap_linear(const uint8_t *src, int srows, int scols, size_t sstride, const float *mapx, const float *mapy,
+                                                      size_t mstride, int rows, int cols, uint8_t *dst, size_t dstride) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= cols || y >= rows) return;
+  const float mx = mapx[(size_t)y * mstride + x], my = mapy[(size_t)y * mstride + x];
+  // cvRound = cvtss2si: out-of-range and NaN inputs give INT_MIN there; __float2int_rn saturates, NaN is patched to match
+  const int sx = (mx != mx || fabsf(mx) >= 67108864.0f) ? INT_MIN : __float2int_rn(__fmul_rn(mx, 32.0f));
+  const int sy = (my != my || fabsf(my) >= 67108864.0f) ? INT_MIN : __float2int_rn(__fmul_rn(my, 32.0f));
+  const int fx = sx & 31, fy = sy & 31;
+  const int ix = min(max(sx >> 5, -32768), 32767), iy = min(max(sy >> 5, -32768), 32767);   // saturate_cast<short>
+  auto tap = [&](int yy, int xx) -> int { return ((unsigned)xx < (unsigned)scols && (unsigned)yy < (unsigned)srows) ? src[(size_t)yy * sstride + xx] : 0; };
+  const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+  const int acc = tap(iy, ix) * w00 + tap(iy, ix + 1) * w01 + tap(iy + 1, ix) * w10 + tap(iy + 1, ix + 1) * w11;
+  dst[(size_t)y * dstride + x] = (uint8_t)((acc + (1 << 14)) >> 15);
+}
+
 // per-frame {n, monoIndex} (ORBextractor.cc:1183 returns monoIndex)
 __global__ void k_counts(FrameParams P) {
   const int frame = blockIdx.x * blockDim.x + threadIdx.x;

@@ -76,6 +76,8 @@ struct orbx_handle {
   FrameParams last{};
   bool have_last = false;
   DevBuf stereo[7];  // grow-only buffers of orbx_compute_stereo_matches
+  DevBuf maps[2];    // rectification maps of orbx_remap_linear, kept between calls
+  int maps_rows = 0, maps_cols = 0;
   // pinned host staging of the single-frame entry point (orbx_extract): pageable copies would serialise on HIP's own staging
   void *pin_in = nullptr, *pin_out = nullptr;
   size_t pin_in_bytes = 0, pin_out_bytes = 0;
@@ -191,6 +193,7 @@ void orbx_destroy(orbx_t *h) {
                     &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
   for (DevBuf *b : bufs) b->release();
   for (DevBuf &b : h->stereo) b.release();
+  for (DevBuf &b : h->maps) b.release();
   if (h->graph) (void)hipGraphExecDestroy(h->graph);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -636,6 +639,84 @@ int orbx_cvt_color_gray(orbx_t *h, const uint8_t *src, int rows, int cols, size_
   XCHECK(h, h->stereo[1].reserve(dpitch * rows));
   XCHECK(h, hipMemcpy2DAsync(h->stereo[0].p, sbytes, src, src_stride, sbytes, (size_t)rows, hipMemcpyHostToDevice, h->stream));
   const int rc = orbx_cvt_color_gray_device((const uint8_t *)h->stereo[0].p, rows, cols, sbytes, channels, rgb_order, (uint8_t *)h->stereo[1].p, dpitch, h->stream);
+  if (rc < 0) return rc;
+  XCHECK(h, hipMemcpy2DAsync(dst, dst_stride, h->stereo[1].p, dpitch, (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int orbx_clahe_device(const uint8_t *d_src, int rows, int cols, size_t src_stride, double clip_limit, int tiles_x, int tiles_y, uint8_t *d_lut,
+                      uint8_t *d_dst, size_t dst_stride, void *stream) {
+  if (!d_src || !d_dst || !d_lut || rows <= 0 || cols <= 0 || tiles_x <= 0 || tiles_y <= 0 || tiles_x * tiles_y > 256 || cols < tiles_x || rows < tiles_y ||
+      src_stride < (size_t)cols || dst_stride < (size_t)cols || !(clip_limit >= 0.0))
+    return ORBX_E_ARG;
+  // CLAHE_Impl::apply: tile size of the (possibly extended) image, lutScale and the integer clip limit
+  const int ecols = cols % tiles_x == 0 ? cols : cols + tiles_x - cols % tiles_x, erows = rows % tiles_y == 0 ? rows : rows + tiles_y - rows % tiles_y;
+  const int tw = ecols / tiles_x, th = erows / tiles_y, tileSizeTotal = tw * th;
+  const float lutScale = (float)255 / (float)tileSizeTotal;
+  int clipLimit = 0;
+  if (clip_limit > 0.0) {
+    clipLimit = (int)(clip_limit * tileSizeTotal / 256);
+    if (clipLimit < 1) clipLimit = 1;
+  }
+  hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, src_stride, tiles_x, tw, th, clipLimit,
+                     lutScale, d_lut);
+  const int rowsPerBlock = 4;
+  hipLaunchKernelGGL(k_clahe_interp, dim3((rows + rowsPerBlock - 1) / rowsPerBlock), dim3(256), (size_t)tiles_x * tiles_y * 256, (hipStream_t)stream, d_src,
+                     rows, cols, src_stride, tiles_x, tiles_y, 1.0f / (float)tw, 1.0f / (float)th, (const uint8_t *)d_lut, d_dst, dst_stride, rowsPerBlock);
+  return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
+}
+
+int orbx_clahe(orbx_t *h, const uint8_t *src, int rows, int cols, size_t src_stride, double clip_limit, int tiles_x, int tiles_y, uint8_t *dst,
+               size_t dst_stride) {
+  if (!h || !src || !dst || rows <= 0 || cols <= 0 || src_stride < (size_t)cols || dst_stride < (size_t)cols) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  const size_t pitch = align_up((size_t)cols, 64);
+  XCHECK(h, h->stereo[0].reserve(pitch * rows));
+  XCHECK(h, h->stereo[1].reserve(pitch * rows));
+  XCHECK(h, h->stereo[2].reserve(256 * 256));
+  XCHECK(h, hipMemcpy2DAsync(h->stereo[0].p, pitch, src, src_stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, h->stream));
+  const int rc = orbx_clahe_device((const uint8_t *)h->stereo[0].p, rows, cols, pitch, clip_limit, tiles_x, tiles_y, (uint8_t *)h->stereo[2].p,
+                                   (uint8_t *)h->stereo[1].p, pitch, h->stream);
+  if (rc < 0) return rc;
+  XCHECK(h, hipMemcpy2DAsync(dst, dst_stride, h->stereo[1].p, pitch, (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, h->stream));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int orbx_remap_linear_device(const uint8_t *d_src, int src_rows, int src_cols, size_t src_stride, const float *d_mapx, const float *d_mapy,
+                             size_t map_stride_elems, int rows, int cols, uint8_t *d_dst, size_t dst_stride, void *stream) {
+  if (!d_src || !d_mapx || !d_mapy || !d_dst || src_rows <= 0 || src_cols <= 0 || rows <= 0 || cols <= 0 || src_stride < (size_t)src_cols ||
+      map_stride_elems < (size_t)cols || dst_stride < (size_t)cols || src_cols > 32767 || src_rows > 32767)
+    return ORBX_E_ARG;
+  hipLaunchKernelGGL(k_remap_linear, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, d_src, src_rows, src_cols, src_stride, d_mapx,
+                     d_mapy, map_stride_elems, rows, cols, d_dst, dst_stride);
+  return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
+}
+
+int orbx_remap_linear(orbx_t *h, const uint8_t *src, int src_rows, int src_cols, size_t src_stride, const float *mapx, const float *mapy, int rows,
+                      int cols, uint8_t *dst, size_t dst_stride) {
+  if (!h || !src || !dst || src_rows <= 0 || src_cols <= 0 || rows <= 0 || cols <= 0 || src_stride < (size_t)src_cols || dst_stride < (size_t)cols ||
+      ((mapx == nullptr) != (mapy == nullptr)))
+    return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  if (mapx) {   // the maps are fixed per camera (computed once, stereo_euroc.cc:113-114): uploaded when given, kept for later calls
+    XCHECK(h, h->maps[0].reserve(sizeof(float) * (size_t)rows * cols));
+    XCHECK(h, h->maps[1].reserve(sizeof(float) * (size_t)rows * cols));
+    XCHECK(h, hipMemcpyAsync(h->maps[0].p, mapx, sizeof(float) * (size_t)rows * cols, hipMemcpyHostToDevice, h->stream));
+    XCHECK(h, hipMemcpyAsync(h->maps[1].p, mapy, sizeof(float) * (size_t)rows * cols, hipMemcpyHostToDevice, h->stream));
+    h->maps_rows = rows;
+    h->maps_cols = cols;
+  } else if (h->maps_rows != rows || h->maps_cols != cols) {
+    h->err = "orbx_remap_linear: no maps of this size uploaded yet";
+    return ORBX_E_ARG;
+  }
+  const size_t spitch = align_up((size_t)src_cols, 64), dpitch = align_up((size_t)cols, 64);
+  XCHECK(h, h->stereo[0].reserve(spitch * src_rows));
+  XCHECK(h, h->stereo[1].reserve(dpitch * rows));
+  XCHECK(h, hipMemcpy2DAsync(h->stereo[0].p, spitch, src, src_stride, (size_t)src_cols, (size_t)src_rows, hipMemcpyHostToDevice, h->stream));
+  const int rc = orbx_remap_linear_device((const uint8_t *)h->stereo[0].p, src_rows, src_cols, spitch, (const float *)h->maps[0].p,
+                                          (const float *)h->maps[1].p, (size_t)cols, rows, cols, (uint8_t *)h->stereo[1].p, dpitch, h->stream);
   if (rc < 0) return rc;
   XCHECK(h, hipMemcpy2DAsync(dst, dst_stride, h->stereo[1].p, dpitch, (size_t)cols, (size_t)rows, hipMemcpyDeviceToHost, h->stream));
   XCHECK(h, hipStreamSynchronize(h->stream));

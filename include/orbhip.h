@@ -119,6 +119,26 @@ int orbx_cvt_color_gray_device(const uint8_t *d_src, int rows, int cols, size_t 
 int orbx_cvt_color_gray(orbx_t *h, const uint8_t *src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *dst,
                         size_t dst_stride);
 
+/* cv::CLAHE::apply for CV_8UC1 as the TUM-VI examples call it on every image before Track* (Examples/Monocular/mono_tum_vi.cc:101-109,
+ * Monocular-Inertial/mono_inertial_tum_vi.cc:128, Stereo-Inertial/stereo_inertial_tum_vi.cc:132: createCLAHE(3.0, Size(8, 8))).
+ * OpenCV 3.4/4.x algorithm: per-tile clipped histogram (excess spread as batch + every residualStep-th bin), cumulative LUT,
+ * float bilinear blend of the four neighbouring tiles' LUTs; sizes that are not a multiple of the tile grid are extended with
+ * BORDER_REFLECT_101 for the histograms.  tiles_x * tiles_y <= 256.  src == dst (in place, as the examples do) is allowed.
+ * *_device: device pointers, asynchronous on stream; d_lut is tiles_x*tiles_y*256 bytes of device scratch. */
+int orbx_clahe_device(const uint8_t *d_src, int rows, int cols, size_t src_stride, double clip_limit, int tiles_x, int tiles_y, uint8_t *d_lut,
+                      uint8_t *d_dst, size_t dst_stride, void *stream);
+int orbx_clahe(orbx_t *h, const uint8_t *src, int rows, int cols, size_t src_stride, double clip_limit, int tiles_x, int tiles_y, uint8_t *dst,
+               size_t dst_stride);
+
+/* cv::remap(src, dst, M1, M2, cv::INTER_LINEAR) with CV_32FC1 maps and the default BORDER_CONSTANT(0): the stereo rectification of
+ * Examples/Stereo/stereo_euroc.cc:166-167 (maps from initUndistortRectifyMap, :113-114, computed once by the caller).
+ * dst is rows x cols like the maps; coordinates are quantised to 1/32 px and blended with OpenCV's 15-bit fixed-point weights.
+ * orbx_remap_linear keeps the uploaded maps: pass mapx = mapy = NULL on later calls to reuse them. */
+int orbx_remap_linear_device(const uint8_t *d_src, int src_rows, int src_cols, size_t src_stride, const float *d_mapx, const float *d_mapy,
+                             size_t map_stride_elems, int rows, int cols, uint8_t *d_dst, size_t dst_stride, void *stream);
+int orbx_remap_linear(orbx_t *h, const uint8_t *src, int src_rows, int src_cols, size_t src_stride, const float *mapx, const float *mapy, int rows,
+                      int cols, uint8_t *dst, size_t dst_stride);
+
 /* void Frame::ComputeStereoMatches()  (Frame.cc:901-1079), rectified stereo - the consumer of mvImagePyramid.
  * left / right: the two extractors (mpORBextractorLeft / Right) AFTER orbx_extract / orbx_extract_batch_device of the
  * two images: their pyramids are still on the device (frame_l / frame_r = index in their last batch), so no image

@@ -511,3 +511,29 @@ def three_maxima(sizes):
     i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
     lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
     return i1.value, i2.value, i3.value
+
+
+def clahe(im, clip_limit=3.0, tiles=(8, 8)):
+    """cv::createCLAHE(clip_limit, Size(tiles))->apply (mono_tum_vi.cc:101-109)."""
+    L = lib()
+    L.orc_clahe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    im = np.ascontiguousarray(im, dtype=np.uint8)
+    out = np.empty_like(im)
+    rc = L.orc_clahe(_p(im), im.shape[0], im.shape[1], im.shape[1], float(clip_limit), int(tiles[0]), int(tiles[1]), _p(out), im.shape[1])
+    if rc != 0:
+        raise ValueError("orc_clahe rc=%d" % rc)
+    return out
+
+
+def remap_linear(im, mapx, mapy):
+    """cv::remap(im, out, mapx, mapy, INTER_LINEAR), CV_32FC1 maps, BORDER_CONSTANT 0 (stereo_euroc.cc:166-167)."""
+    L = lib()
+    L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    im = np.ascontiguousarray(im, dtype=np.uint8)
+    mapx = np.ascontiguousarray(mapx, dtype=np.float32); mapy = np.ascontiguousarray(mapy, dtype=np.float32)
+    H, W = mapx.shape
+    out = np.empty((H, W), np.uint8)
+    rc = L.orc_remap_linear(_p(im), im.shape[0], im.shape[1], im.shape[1], _p(mapx), _p(mapy), W, H, W, _p(out), W)
+    if rc != 0:
+        raise ValueError("orc_remap_linear rc=%d" % rc)
+    return out

@@ -2160,3 +2160,133 @@ int orc_distinctive_descriptor(const uint8_t *desc, int N) {
   free(v); free(D);
   return BestIdx;
 }
+
+
+/* ---- N4: the image operations the Examples apply before Track* --------------------------------------------------------------
+ * Both are OpenCV (third-party, absent here) algorithms, restated from their published sources: [OPENCV-UNVERIFIED]. */
+
+/* cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply(src, dst), CV_8UC1 (Examples/Monocular/mono_tum_vi.cc:101-109).
+ * OpenCV 3.4 / 4.x modules/imgproc/src/clahe.cpp: CLAHE_Impl::apply, CLAHE_CalcLut_Body, CLAHE_Interpolation_Body. */
+static uint8_t sat_u8_f(float v) {
+  long r = lrintf(v);   /* cvRound: round half to even */
+  return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+int orc_clahe(const uint8_t *src, int rows, int cols, size_t sstride, double clipLimit_, int tilesX, int tilesY, uint8_t *dst, size_t dstride) {
+  enum { histSize = 256 };
+  if (rows <= 0 || cols <= 0 || tilesX <= 0 || tilesY <= 0 || cols < tilesX || rows < tilesY) return -1;
+  /* apply(): extend to a multiple of the tile grid with BORDER_REFLECT_101 (bottom / right only) when needed */
+  const int ecols = cols % tilesX == 0 ? cols : cols + (tilesX - cols % tilesX);
+  const int erows = rows % tilesY == 0 ? rows : rows + (tilesY - rows % tilesY);
+  const int tw = ecols / tilesX, th = erows / tilesY;
+  const int tileSizeTotal = tw * th;
+  const float lutScale = (float)(histSize - 1) / tileSizeTotal;
+  int clipLimit = 0;
+  if (clipLimit_ > 0.0) {
+    clipLimit = (int)(clipLimit_ * tileSizeTotal / histSize);
+    if (clipLimit < 1) clipLimit = 1;
+  }
+  uint8_t *lut = (uint8_t *)malloc((size_t)tilesX * tilesY * histSize);
+  for (int k = 0; k < tilesX * tilesY; k++) {
+    const int ty = k / tilesX, tx = k % tilesX;
+    int tileHist[histSize];
+    memset(tileHist, 0, sizeof(tileHist));
+    for (int y = ty * th; y < (ty + 1) * th; y++)
+      for (int x = tx * tw; x < (tx + 1) * tw; x++) tileHist[src[(size_t)reflect101(y, rows) * sstride + reflect101(x, cols)]]++;
+    if (clipLimit > 0) {
+      int clipped = 0;
+      for (int i = 0; i < histSize; i++)
+        if (tileHist[i] > clipLimit) { clipped += tileHist[i] - clipLimit; tileHist[i] = clipLimit; }
+      const int redistBatch = clipped / histSize;
+      int residual = clipped - redistBatch * histSize;
+      for (int i = 0; i < histSize; i++) tileHist[i] += redistBatch;
+      if (residual != 0) {
+        const int residualStep = histSize / residual > 1 ? histSize / residual : 1;
+        for (int i = 0; i < histSize && residual > 0; i += residualStep, residual--) tileHist[i]++;
+      }
+    }
+    int sum = 0;
+    for (int i = 0; i < histSize; i++) { sum += tileHist[i]; lut[(size_t)k * histSize + i] = sat_u8_f(sum * lutScale); }
+  }
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  for (int y = 0; y < rows; y++) {
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    if (ty1 < 0) ty1 = 0;
+    if (ty2 > tilesY - 1) ty2 = tilesY - 1;
+    const uint8_t *lutPlane1 = lut + (size_t)ty1 * tilesX * histSize, *lutPlane2 = lut + (size_t)ty2 * tilesX * histSize;
+    for (int x = 0; x < cols; x++) {
+      const float txf = x * inv_tw - 0.5f;
+      int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+      const float xa = txf - tx1, xa1 = 1.0f - xa;
+      if (tx1 < 0) tx1 = 0;
+      if (tx2 > tilesX - 1) tx2 = tilesX - 1;
+      const int srcVal = src[(size_t)y * sstride + x];
+      const int ind1 = tx1 * histSize + srcVal, ind2 = tx2 * histSize + srcVal;
+      const float res = (lutPlane1[ind1] * xa1 + lutPlane1[ind2] * xa) * ya1 + (lutPlane2[ind1] * xa1 + lutPlane2[ind2] * xa) * ya;
+      dst[(size_t)y * dstride + x] = sat_u8_f(res);
+    }
+  }
+  free(lut);
+  return 0;
+}
+
+/* cv::remap(src, dst, map1 (CV_32FC1 x), map2 (CV_32FC1 y), INTER_LINEAR, BORDER_CONSTANT, Scalar()) for CV_8UC1
+ * (Examples/Stereo/stereo_euroc.cc:166-167).  OpenCV imgwarp.cpp: RemapInvoker converts the float maps to fixed point
+ * (INTER_BITS = 5), remapBilinear<FixedPtCast<int, uchar, 15>> blends with the BilinearTab_i weights.  The table is built here
+ * the way initInterTab2D does (float products, saturate_cast<short>(v * 32768)); every product is a multiple of 1/1024, so the
+ * weights are exact and sum to 1 << 15 except at fx = fy = 0 (see below). */
+static int cv_round_f(float v) {
+  if (!(v > -2147483648.0f && v < 2147483648.0f)) return INT32_MIN;   /* cvtss2si "integer indefinite" */
+  return (int)lrintf(v);
+}
+static short sat_s16(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+int orc_remap_linear(const uint8_t *src, int srows, int scols, size_t sstride, const float *mapx, const float *mapy, size_t mstride, int rows,
+                     int cols, uint8_t *dst, size_t dstride) {
+  enum { INTER_BITS = 5, INTER_TAB_SIZE = 32, COEF_BITS = 15, COEF_SCALE = 1 << 15 };
+  static short wtab[INTER_TAB_SIZE * INTER_TAB_SIZE][4];
+  float t1[INTER_TAB_SIZE][2];
+  for (int i = 0; i < INTER_TAB_SIZE; i++) { const float x = i * (1.f / INTER_TAB_SIZE); t1[i][0] = 1.f - x; t1[i][1] = x; }
+  for (int i = 0; i < INTER_TAB_SIZE; i++)
+    for (int j = 0; j < INTER_TAB_SIZE; j++) {
+      int isum = 0;
+      for (int k1 = 0; k1 < 2; k1++)
+        for (int k2 = 0; k2 < 2; k2++) {
+          const float v = t1[i][k1] * t1[j][k2];
+          isum += wtab[i * INTER_TAB_SIZE + j][k1 * 2 + k2] = sat_s16((int)lrintf(v * COEF_SCALE));
+        }
+      /* initInterTab2D's correction step: only the entry fx = fy = 0 needs it (1.0 * 32768 saturates to 32767, isum = 32767);
+       * it looks for the extreme weight among table positions [ksize/2, ksize/2 + 2)^2, which for ksize = 2 starts at the
+       * entry's last weight, and adds the missing 1 there: {32767, 0, 0, 1}.  No output depends on it: with taps a, b in 0..255,
+       * (32767 a + b + 16384) >> 15 == a. */
+      if (isum != COEF_SCALE) {
+        if (i != 0 || j != 0 || isum != COEF_SCALE - 1) return -2;
+        wtab[0][3] = (short)(wtab[0][3] + 1);
+      }
+    }
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      const int sxq = cv_round_f(mapx[(size_t)y * mstride + x] * INTER_TAB_SIZE), syq = cv_round_f(mapy[(size_t)y * mstride + x] * INTER_TAB_SIZE);
+      const int v = (syq & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (sxq & (INTER_TAB_SIZE - 1));
+      const int sx = sat_s16(sxq >> INTER_BITS), sy = sat_s16(syq >> INTER_BITS);
+      const short *w = wtab[v];
+      int val;
+      if ((unsigned)sx < (unsigned)(scols - 1 > 0 ? scols - 1 : 0) && (unsigned)sy < (unsigned)(srows - 1 > 0 ? srows - 1 : 0)) {
+        const uint8_t *S = src + (size_t)sy * sstride + sx;
+        val = S[0] * w[0] + S[1] * w[1] + S[sstride] * w[2] + S[sstride + 1] * w[3];
+      } else if (sx >= scols || sx + 1 < 0 || sy >= srows || sy + 1 < 0) {
+        dst[(size_t)y * dstride + x] = 0;
+        continue;
+      } else {
+        const int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
+        const int v0 = (sx0 >= 0 && sy0 >= 0 && sx0 < scols && sy0 < srows) ? src[(size_t)sy0 * sstride + sx0] : 0;
+        const int v1 = (sx1 >= 0 && sy0 >= 0 && sx1 < scols && sy0 < srows) ? src[(size_t)sy0 * sstride + sx1] : 0;
+        const int v2 = (sx0 >= 0 && sy1 >= 0 && sx0 < scols && sy1 < srows) ? src[(size_t)sy1 * sstride + sx0] : 0;
+        const int v3 = (sx1 >= 0 && sy1 >= 0 && sx1 < scols && sy1 < srows) ? src[(size_t)sy1 * sstride + sx1] : 0;
+        val = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+      }
+      val = (val + (1 << (COEF_BITS - 1))) >> COEF_BITS;
+      dst[(size_t)y * dstride + x] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
+    }
+  return 0;
+}

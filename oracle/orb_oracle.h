@@ -255,6 +255,12 @@ void orc_three_maxima(const int *histo_sizes, int L, int *ind1, int *ind2, int *
 /* RadiusByViewingCos, ORBmatcher.cc:216-222. */
 float orc_radius_by_viewing_cos(float viewCos);
 
+/* N4: cv::CLAHE::apply (mono_tum_vi.cc:101-109) and cv::remap INTER_LINEAR with float maps (stereo_euroc.cc:166-167), CV_8UC1.
+ * OpenCV algorithms restated from the published 3.4/4.x sources: [OPENCV-UNVERIFIED]. */
+int orc_clahe(const uint8_t *src, int rows, int cols, size_t sstride, double clipLimit, int tilesX, int tilesY, uint8_t *dst, size_t dstride);
+int orc_remap_linear(const uint8_t *src, int srows, int scols, size_t sstride, const float *mapx, const float *mapy, size_t mstride, int rows,
+                     int cols, uint8_t *dst, size_t dstride);
+
 #ifdef __cplusplus
 }
 #endif

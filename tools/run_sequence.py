@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--times", default=None)
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--clahe", action="store_true", help="apply createCLAHE(3.0, Size(8, 8)) to every image first, as mono_tum_vi.cc:101-109 does")
     ap.add_argument("--csv", default="gpurun_out/sequence.csv")
     args = ap.parse_args()
     if args.euroc and not args.times:
@@ -57,6 +58,8 @@ def main():
     for name, im in load_frames(args, synth):
         if im.ndim == 3:
             im = ex.cvtColorGray(im, rgb=True)          # Tracking.cc:1122-1135
+        if args.clahe:
+            im = ex.CLAHE(im, 3.0, (8, 8))              # mono_tum_vi.cc:101-109
         t0 = time.perf_counter()
         _, kps, desc = ex(im, None, (0, 0))
         t1 = time.perf_counter()
