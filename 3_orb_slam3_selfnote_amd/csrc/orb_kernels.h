@@ -84,6 +84,15 @@ __device__ __forceinline__ void xcd_map(int nitems, uint32_t magic, int nframes,
 // All 64 lanes must be active.
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false); }
+// Low 32 bits of a 24 x 24-bit product: v_mul_u32_u24, full rate (v_mul_lo_u32 / v_mul_hi_u32 issue at a quarter of it).
+// Inline assembly because the instruction selector only forms it when it can prove both operands 24-bit, which it cannot
+// for loop indices bounded by a compare.  mul24(a, u): u wave-uniform (scalar operand).
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t u) {
+  uint32_t d;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "s"(u), "v"(a));
+  return d;
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += dpp_or_zero<0x111, 0xf>(v);
   v += dpp_or_zero<0x112, 0xf>(v);
@@ -165,14 +174,18 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   __shared__ int2 sY[RESIZE_ROWS];
   if (tid < nrows) sY[tid] = P.ytab[G.ytabBase + dy0 + tid];
   const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
+  // Index arithmetic: 32-bit integer multiplies issue at a quarter of the full rate, so idx / ndw is taken in float --
+  // (idx + 0.5) / ndw stays at least 0.5 / ndw >= 2^-11 away from an integer while the rounding error of the product is
+  // below 2^-19 for idx < 2^14, so truncation yields the exact quotient -- and offsets use 24-bit multiplies (mul24).
   if (nsrc <= RESIZE_MAXSRC) {
+    const uint8_t *src0 = src + (size_t)syFirst * spitch;
     if (aligned) {
       const int ndw = (Gs.w + 3) >> 2;  // the last dword may read up to 3 bytes of row padding / next row: inside the plane
       const bool lastRowPartial = (Gs.w & 3) != 0;
-      const uint32_t mg = 0xffffffffu / (uint32_t)ndw + 1u;
+      const float inv_ndw = 1.0f / (float)ndw;
       for (int idx = tid; idx < ndw * nsrc; idx += 256) {
-        const int r = (int)__umulhi((uint32_t)idx, mg), d = idx - r * ndw;
-        const uint8_t *rowp = src + (size_t)(syFirst + r) * spitch;
+        const int r = (int)(((float)idx + 0.5f) * inv_ndw), d = idx - (int)mul24((uint32_t)r, (uint32_t)ndw);
+        const uint8_t *rowp = src0 + mul24((uint32_t)r, (uint32_t)spitch);
         uint32_t v;
         if (lastRowPartial && d == ndw - 1 && syFirst + r == Gs.h - 1 && spitch < 4 * ndw) {
           v = 0;  // very last bytes of the plane: do not read past the allocation
@@ -180,24 +193,27 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
         } else {
           v = *reinterpret_cast<const uint32_t *>(rowp + 4 * d);
         }
-        *reinterpret_cast<uint32_t *>(sRows + (size_t)r * smemRowBytes + 4 * d) = v;
+        *reinterpret_cast<uint32_t *>(sRows + mul24((uint32_t)r, (uint32_t)smemRowBytes) + 4 * d) = v;
       }
     } else {
+      const float inv_w = 1.0f / (float)Gs.w;
       for (int idx = tid; idx < Gs.w * nsrc; idx += 256) {
-        const int r = idx / Gs.w, c = idx - r * Gs.w;
-        sRows[(size_t)r * smemRowBytes + c] = src[(size_t)(syFirst + r) * spitch + c];
+        const int r = (int)(((float)idx + 0.5f) * inv_w), c = idx - (int)mul24((uint32_t)r, (uint32_t)Gs.w);
+        sRows[mul24((uint32_t)r, (uint32_t)smemRowBytes) + c] = src0[mul24((uint32_t)r, (uint32_t)spitch) + c];
       }
     }
   }
   __syncthreads();
   uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
   const int qw = (G.w + 3) >> 2;
-  const uint32_t mq = 0xffffffffu / (uint32_t)qw + 1u;
+  // q / qw in float: (q + 0.5) / qw is at least 0.5 / qw >= 2^-11 away from an integer, the product's rounding error is
+  // below 2^-19 for q < 8 * 1024, so truncation gives the exact quotient (four full-rate operations)
+  const float inv_qw = 1.0f / (float)qw;
   // The row loop is instantiated twice so that the source gathers are ds_read_u8 (LDS) or global_load_ubyte; one loop
   // with a run-time pointer select compiles to FLAT loads that wait on both counters.
   auto rows = [&](auto srcRow) {
     for (int q = tid; q < qw * nrows; q += 256) {
-      const int ry = (int)__umulhi((uint32_t)q, mq), dx0 = (q - ry * qw) * 4, dy = dy0 + ry;
+      const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
       const int2 yt = sY[ry];
       const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
       const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
@@ -215,13 +231,13 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
         v = min(max(v, 0), 255);
         packed |= (uint32_t)v << (8 * j);
       }
-      uint8_t *dst = dstplane + (size_t)dy * G.pitch;
+      uint8_t *dst = dstplane + mul24((uint32_t)dy, (uint32_t)G.pitch);
       if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
       else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
     }
   };
-  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + (size_t)(sy - syFirst) * smemRowBytes; });
-  else rows([&](int sy) { return src + (size_t)sy * spitch; });  // extreme scale factors: straight from global
+  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + mul24((uint32_t)(sy - syFirst), (uint32_t)smemRowBytes); });
+  else rows([&](int sy) { return src + mul24((uint32_t)sy, (uint32_t)spitch); });  // extreme scale factors: straight from global
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -288,6 +304,8 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
 #ifndef FAST_NT
 #define FAST_NT 256
 #endif
+#define FAST_LIST_SEG 900   // list entries per wavefront: 15 rows x 60 columns (64-lane rows), 16 rows x 32 (32-lane rows)
+static_assert(FAST_NT == 256, "k_fast's list segments assume four wavefronts");
 // Diagnostic builds (-DFAST_STAMPS, tools/fast_stamps.py): cycles per section, thread 0 of every workgroup.
 #ifdef FAST_STAMPS
 __device__ unsigned int *g_fast_stamps;  // [workgroup][8] cycle deltas, set by orbx_debug_fast_stamps
@@ -301,9 +319,10 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 #endif
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
-  __shared__ uint16_t sList[60 * 60];
+  __shared__ uint16_t sList[4 * FAST_LIST_SEG];
   __shared__ uint32_t sKept[1024];
-  __shared__ uint32_t sCount, sNList, sNKept, sNOut;
+  __shared__ uint32_t sCount, sNKept, sNOut;
+  __shared__ __align__(16) uint32_t sWCount[4];
   const int tid = threadIdx.x, lane = tid & 63;
   int cellId, frame;
   xcd_map(P.totalCells, P.magicCells, P.nframes, frame, cellId);
@@ -328,48 +347,66 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   const int ax = iniX & ~3, ox = iniX - ax;           // ox: offset of the cell's first column inside the tile
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
   if (aligned) {
+    // Index arithmetic in 24-bit multiplies (full rate; 32-bit integer multiplies issue at a quarter of it): idx / ndw as
+    // (idx * M) >> 20 with M = 2^20 / ndw + 1, exact for idx < 4096 and ndw < 256; row offsets fit 32 bits (planes <= 4096^2).
     const int ndw = (ox + tw + 3) >> 2;               // dwords per tile row (<= 18)
-    const uint32_t magic = 0xffffffffu / (uint32_t)ndw + 1u;
+    const uint32_t magic = (1u << 20) / (uint32_t)ndw + 1u;
+    const uint8_t *img0 = img + mul24((uint32_t)iniY, (uint32_t)pitch) + ax;
     for (int idx = tid; idx < ndw * th; idx += FAST_NT) {
-      const int r = (int)__umulhi((uint32_t)idx, magic), d = idx - r * ndw;
+      const uint32_t r = mul24((uint32_t)idx, magic) >> 20, d = (uint32_t)idx - mul24(r, (uint32_t)ndw);
       // the last dword of a row may reach past the image row; it stays inside the plane's pitch padding / next row
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(img + (size_t)(iniY + r) * pitch + ax + 4 * d);
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(img0 + (mul24(r, (uint32_t)pitch) + 4u * d));
       *reinterpret_cast<uint32_t *>(&sT[r * FAST_TILE_PITCH + 4 * d]) = v;
     }
   } else {
-    const uint32_t magic = 0xffffffffu / (uint32_t)tw + 1u;
+    const uint32_t magic = (1u << 20) / (uint32_t)tw + 1u;
+    const uint8_t *img0 = img + mul24((uint32_t)iniY, (uint32_t)pitch) + iniX;
     for (int idx = tid; idx < tw * th; idx += FAST_NT) {
-      const int r = (int)__umulhi((uint32_t)idx, magic), cc = idx - r * tw;
-      sT[r * FAST_TILE_PITCH + ox + cc] = img[(size_t)(iniY + r) * pitch + iniX + cc];
+      const uint32_t r = mul24((uint32_t)idx, magic) >> 20, cc = (uint32_t)idx - mul24(r, (uint32_t)tw);
+      sT[r * FAST_TILE_PITCH + ox + cc] = img0[mul24(r, (uint32_t)pitch) + cc];
     }
   }
   for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
-  if (tid == 0) { sCount = 0; sNList = 0; sNKept = 0; sNOut = 0; }
+  if (tid == 0) { sCount = 0; sNKept = 0; sNOut = 0; }
   __syncthreads();
   FSTAMP(0);
   const int tmin = min(P.iniTh, P.minTh);
-  const uint32_t magicw = 0xffffffffu / (uint32_t)cw + 1u;  // p / cw for p < 2^16 (exact: p*cw < 2^32)
-  // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list
-  for (int p0 = 0; p0 < cw * ch; p0 += FAST_NT) {
-    const int p = p0 + tid;
-    bool pass = false;
-    if (p < cw * ch) {
-      const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
-      pass = fast_compass_test(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3], tmin);
-    }
-    const unsigned long long b = __ballot(pass);
-    uint32_t wbase = 0;
-    if (lane == 0 && b) wbase = atomicAdd(&sNList, (uint32_t)__popcll(b));
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-    if (pass) sList[wbase + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
+  // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list as y << 6 | x (raster order = numeric order).
+  // Threads form rows of 32 (cells up to 32 interior columns, the usual 30) or 64 lanes and step down the cell, so the
+  // per-pixel index arithmetic is one add; a linear pixel index would need a division per pixel.
+  const int xsh = cw <= 32 ? 5 : 6;
+  const int px = tid & ((1 << xsh) - 1), py = tid >> xsh, yStep = FAST_NT >> xsh;
+  const bool xin = px < cw;
+  const uint8_t *c0 = &sT[(py + 3) * FAST_TILE_PITCH + ox + px + 3];
+  // Every wavefront appends to its own segment of the list (at most ceil(ch / yStep) rows x cw entries <= FAST_LIST_SEG) and
+  // keeps its count in a scalar register: no atomics.
+  uint16_t *myList = sList + (tid >> 6) * FAST_LIST_SEG;
+  const unsigned long long laneLt = (1ull << lane) - 1ull;
+  int wcount = 0;
+  for (int y0 = 0; y0 < ch; y0 += yStep) {
+    const int y = y0 + py;
+    // lanes outside the cell read LDS bytes that mean nothing (or zero past the allocation) and are masked out afterwards
+    const bool pass = fast_compass_test(c0 + y0 * FAST_TILE_PITCH, tmin) & xin & (y < ch);
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(pass);
+    if (pass) myList[wcount + __popcll(b & laneLt)] = (uint16_t)((y << 6) | px);
+    wcount += __popcll(b);
   }
+  if (lane == 0) sWCount[tid >> 6] = (uint32_t)wcount;
   __syncthreads();
   FSTAMP(1);
+  // The four segments are walked as one list by all 256 threads (a wavefront walking only its own segment would need a
+  // second trip whenever that segment alone exceeds 64 entries): entry e lives in segment #(prefix sums <= e).
+  const uint4 wc = *reinterpret_cast<const uint4 *>(sWCount);
+  const int pre1 = (int)wc.x, pre2 = pre1 + (int)wc.y, pre3 = pre2 + (int)wc.z, nlist = pre3 + (int)wc.w;
+  auto entry = [&](int e) -> int {
+    const int seg = (e >= pre1) + (e >= pre2) + (e >= pre3);
+    const int start = e >= pre2 ? (e >= pre3 ? pre3 : pre2) : (e >= pre1 ? pre1 : 0);
+    return sList[seg * FAST_LIST_SEG + (e - start)];
+  };
   // ---- pass 2: full 16-pixel score for the survivors only
-  const int nlist = (int)sNList;
   for (int e = tid; e < nlist; e += FAST_NT) {
-    const int p = sList[e];
-    const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
+    const int p = entry(e);
+    const int y = p >> 6, x = p & 63;
     const int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3]);
     sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
   }
@@ -378,8 +415,8 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list; vote for
   // the iniThFAST set.  Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
   for (int e = tid; e < nlist; e += FAST_NT) {
-    const int p = sList[e];
-    const int y = (int)__umulhi((uint32_t)p, magicw), x = p - y * cw;
+    const int p = entry(e);
+    const int y = p >> 6, x = p & 63;
     const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
     const int S = s[0];
     const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     const uint32_t v = sOut[e], p = v & 0xffffu;
     uint32_t rank = 0;
     for (int i = 0; i < nout; i++) rank += ((sOut[i] & 0xffffu) < p) ? 1u : 0u;
-    const int y = (int)__umulhi(p, magicw), x = (int)p - y * cw;
+    const int y = (int)(p >> 6), x = (int)(p & 63u);
     const uint32_t X = baseX + (uint32_t)(x + 3), Y = baseY + (uint32_t)(y + 3);
     if (rank < cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
   }

@@ -176,24 +176,41 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   auto c7 = [](int v) { return (uint32_t)min(max(v, 0), 127); };
   const uint32_t LO = c7(minlE) | (c7(w.cx0) << 8) | (c7(w.cy0) << 16);
   const uint32_t HI7 = (c7(maxlE) | (c7(w.cx1) << 8) | (c7(w.cy1) << 16)) | 0x808080u;
+  K pend = KT::NONE;
+  auto insert = [&](K t) {   // sorted insertion into top[]; a no-op for t = NONE
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) {
+      const K lo = t < top[j] ? t : top[j];
+      const K hi = t < top[j] ? top[j] : t;
+      top[j] = lo;
+      t = hi;
+    }
+  };
   for (int base = 0; base < n; base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
     __syncthreads();
     if (tid < 2 * m) sDesc[tid] = desc[(size_t)base * 2 + tid];
-    if (tid < m) {
-      const int i = base + tid;
-      CandMeta c;
-      c.x = kp[(size_t)i * 7];
-      c.y = kp[(size_t)i * 7 + 1];
-      const int oct = __float_as_int(kp[(size_t)i * 7 + 5]);
-      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
-      const bool claimed = M.slot[fo + i] >= 0 && M.slot_obs[fo + i];
-      c.bits = cand_bits(c.x, c.y, oct, claimed, M);
+    const int m4 = (m + 3) & ~3;   // the candidate loop runs four at a time; the tail is padded with unusable entries (bits = 0)
+    if (tid < m4) {
+      CandMeta c = {0.f, 0.f, 0u, -1.f};
+      if (tid < m) {
+        const int i = base + tid;
+        c.x = kp[(size_t)i * 7];
+        c.y = kp[(size_t)i * 7 + 1];
+        const int oct = __float_as_int(kp[(size_t)i * 7 + 5]);
+        c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
+        const bool claimed = M.slot[fo + i] >= 0 && M.slot_obs[fo + i];
+        c.bits = cand_bits(c.x, c.y, oct, claimed, M);
+      }
       sMeta[tid] = c;
     }
     __syncthreads();
     if (w.live) {
-      for (int c = 0; c < m; c++) {
+      const int m4u = __builtin_amdgcn_readfirstlane(m4);
+      for (int c0 = 0; c0 < m4u; c0 += 4)
+#pragma unroll
+      for (int cu = 0; cu < 4; cu++) {
+        const int c = c0 + cu;
         const CandMeta cm = sMeta[c];
         // cand_passes() in sign-bit arithmetic (one compare at the end instead of a dozen compare/and chains):
         // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
@@ -213,7 +230,8 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           if (cm.ur >= 0.f) { const float er = w.ur - cm.ur; e2 = e2 + er * er; lim = 7.8; }
           ok = ok && !((double)(e2 * M.inv_sigma2[oct & 15]) > lim);
         }
-        if (ok) {
+        // Uniform branch: a divergent region would cost the same issue slots, and the wavefront-wide votes below need all lanes.
+        if (__builtin_amdgcn_ballot_w64(ok)) {
           const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
           // one accumulating v_bcnt_u32_b32 per word: two independent chains of four, one add (the compiler's own
           // choice is eight zero-based counts plus an add tree: three more vector instructions per candidate)
@@ -222,20 +240,25 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
           d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
           const int dist = d0 + d1;
-          K t = KT::make(dist, cell_of(cm.bits), base + c);
-          if (t < top[MATCH_TOPK - 1]) {
-#pragma unroll
-            for (int j = 0; j < MATCH_TOPK; j++) {
-              const K lo = t < top[j] ? t : top[j];
-              const K hi = t < top[j] ? top[j] : t;
-              top[j] = lo;
-              t = hi;
+          const K t = ok ? KT::make(dist, cell_of(cm.bits), base + c) : KT::NONE;
+          const bool pass = t < top[MATCH_TOPK - 1];
+          // A key below the lane's current 8th best is parked in `pend`; the sorted insertion (16 min/max) runs for the whole
+          // wavefront only when some lane would have to park a second one.  With 64 lanes nearly every candidate improves
+          // SOME lane's list, so inserting on the spot executes the network for almost every candidate; parked, it runs
+          // about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
+          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
+          if (passMask) {
+            if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
+              insert(pend);
+              pend = KT::NONE;
             }
+            pend = pass ? t : pend;
           }
         }
       }
     }
   }
+  insert(pend);
   if (q < nq) {
     K *o = topk + (qo + q) * MATCH_TOPK;
 #pragma unroll
