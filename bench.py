@@ -254,6 +254,26 @@ def main():
         except Exception:
             traffic = None
 
+    # VALU issue roofline of the whole step: wave-instructions per launch from the committed SQ_INSTS_VALU profile (a separate
+    # rocprofv3 --pmc run of this same workload, tools/collect_sq.py), time measured here.  A wave64 instruction occupies its
+    # SIMD for 4 cycles; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock issue at most 614.4 G wave-instructions/s.
+    valu = None
+    sf = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(sf) and B == 256 and not args.no_match:
+        try:
+            sj = json.load(open(sf))
+            tot = 0.0
+            for stage, (kn, launches) in kernels.items():
+                hit = [v for k, v in sj.items() if kn in k and "SQ_INSTS_VALU" in v]
+                tot += max(h["SQ_INSTS_VALU"] for h in hit) * launches if hit else 0.0
+            peak = 256 * 4 * 2.4e9 / 4
+            ach_i = tot / (dt / args.steps)
+            valu = {"bound": "valu-issue", "achieved": round(ach_i / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                    "frac": round(ach_i / peak, 4), "wave_instructions_per_step": round(tot),
+                    "source": "profiles/sq_counters.json (SQ_INSTS_VALU per launch, separate --pmc run); time measured live"}
+        except Exception:
+            valu = None
+
     if rank == 0:
         out = {
             "metric": "frames/sec ORB extract+match, 752x480" if not args.no_match else "frames/sec ORB extract, 752x480",
@@ -275,6 +295,8 @@ def main():
                                       "stage_ms_per_step": {k: round(v, 4) for k, v in iso.items()}},
                          "pipeline_algorithmic_GBps": round(fps / world * total_bytes / 1e9, 2)},
         }
+        if valu is not None and world == 1:
+            out["roofline"]["valu_issue"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, offs)
         print(json.dumps(out))
