@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
-    ap.add_argument("--streams", type=int, default=3, help="independent pipelines on separate HIP streams (steps alternate)")
+    ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (steps alternate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1])")
     args = ap.parse_args()
