@@ -974,6 +974,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (!m || !f || !q || npairs <= 0 || !d_slot || !d_slot_obs) return ORBX_E_ARG;
   if (!f->keys_un || !f->descriptors || !q->descriptors || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level) return ORBX_E_ARG;
   if (!(f->max_x > f->min_x) || !(f->max_y > f->min_y)) return ORBX_E_ARG;
+  // bestDist starts at 256 in the reference: a threshold >= 256 would "accept" a query without any candidate (index -1 there)
+  if (th_dist < 0 || th_dist > 255) { m->err = "th_dist must be in [0, 255]"; return ORBX_E_ARG; }
   MCHECK(m, hipSetDevice(m->device));
   hipStream_t s = (hipStream_t)stream_;  // verbatim: NULL is the device's default stream
   MatchProblemSet M;

@@ -60,7 +60,11 @@ int orbx_get_features_per_level(const orbx_t *h, int *nPerLevel);
 
 /* Size the device workspace for `max_batch` frames of rows x cols.  Called implicitly by the extract entry points
  * when the geometry changes.  Returns the per-frame keypoint capacity bound (sum over levels of the octree's
- * maximum output), which is what `cap` must be >= for orbx_extract* never to return ORBX_E_CAP. */
+ * maximum output), which is what `cap` must be >= for orbx_extract* never to return ORBX_E_CAP.
+ * Limits (ORBX_E_ARG with orbx_last_error otherwise): images up to 4096 x 4096, batches up to 65535 frames, and a
+ * per-level feature quota (mnFeaturesPerLevel, ORBextractor.cc:432-443) of about 2200 -- DistributeOctTree's node list of a
+ * level lives in the 160 KB of LDS; the reference's settings (1000-2000 features, the 5x initialisation extractor at 8
+ * levels) stay below it. */
 int orbx_configure(orbx_t *h, int rows, int cols, int max_batch);
 int orbx_max_keypoints(const orbx_t *h);
 
@@ -196,6 +200,7 @@ typedef struct {
 /* Projection search core shared by the five ORBmatcher::SearchByProjection overloads.
  * use_second != 0: best/second-best with the same-level ratio test of ORBmatcher.cc:104-129 (M2);
  * use_second == 0: strict-less argmin with threshold th_dist (M3 :2152-2162, M4 :2362-2371, M5 :586-600).
+ * th_dist in [0, 255] (ORBX_E_ARG otherwise: at 256 the reference would accept a query that has no candidate at all).
  * slot[n] (in/out): query id holding keypoint i, -1 = free (F.mvpMapPoints); slot_obs[n] (in/out): 1 if that
  * holder has Observations()>0.  match_of_query[nq] (out, may be NULL); best_dist[nq] (out, may be NULL) = distance
  * of the best unclaimed candidate when it is <= th_dist, else 256.

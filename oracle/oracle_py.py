@@ -265,6 +265,8 @@ class OracleFrame:
     def search_by_projection_win(self, qdesc, u, v, radius, min_level, max_level, nnratio=0.8, th_high=100,
                                  mode_second=True, qobs=None, in_view=None):
         nq = len(u)
+        if not 0 <= th_high <= 255:
+            raise ValueError("th_high >= 256 accepts a query without candidates: index -1 in the reference (undefined)")
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
         qdesc, u, v, radius = a(qdesc, np.uint8), a(u, np.float32), a(v, np.float32), a(radius, np.float32)
         min_level, max_level = a(min_level, np.int32), a(max_level, np.int32)

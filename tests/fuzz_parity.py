@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (run ON THE GPU BOX from the repo root):  python tests/fuzz_parity.py [--n 200] [--seed 1]
+
+Draws random extractor configurations (image size, nfeatures, scaleFactor, nlevels, thresholds, lapping area, image
+statistics) and random window-search problems (query count, radii, level windows, pre-occupied keypoints, observation
+flags, ratio / distance thresholds), runs each through the C ABI and through the CPU oracle and reports every
+difference.  Test infrastructure: the oracle is only the checker here.  Exit status 1 on any mismatch."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def random_image(rng, H, W, synth):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        return synth.make_frame(int(rng.integers(1, 1 << 30)), H, W)
+    if kind == 1:   # noise: corners everywhere, quotas and the octree are stressed
+        return rng.integers(0, 256, (H, W), dtype=np.uint8)
+    if kind == 2:   # low contrast: the per-cell minThFAST fallback decides
+        base = synth.make_frame(int(rng.integers(1, 1 << 30)), H, W).astype(np.int32)
+        return (128 + (base - 128) // int(rng.integers(3, 9))).clip(0, 255).astype(np.uint8)
+    if kind == 3:   # blocks: many equal scores (NMS and octree ties)
+        s = int(rng.integers(4, 17))
+        small = rng.integers(0, 4, ((H + s - 1) // s, (W + s - 1) // s), dtype=np.uint8) * 80
+        return np.kron(small, np.ones((s, s), np.uint8))[:H, :W].copy()
+    img = synth.make_frame(int(rng.integers(1, 1 << 30)), H, W)   # half flat: empty cells and levels
+    img[:, W // 2:] = 90
+    return img
+
+
+def fuzz_extract(pkg, oracle, synth, rng, log):
+    H, W = int(rng.integers(96, 640)), int(rng.integers(96, 800))
+    cfg = dict(nfeatures=int(rng.choice([30, 200, 500, 1000, 1500, 3000])), scaleFactor=float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0])),
+               nlevels=int(rng.integers(1, 9)), iniThFAST=int(rng.integers(8, 41)), minThFAST=int(rng.integers(2, 12)))
+    if cfg["minThFAST"] > cfg["iniThFAST"]:
+        cfg["minThFAST"] = cfg["iniThFAST"]
+    img = random_image(rng, H, W, synth)
+    lap = (0, 0) if rng.random() < 0.5 else tuple(sorted(int(v) for v in rng.integers(0, W, 2)))
+    try:
+        e = pkg.ORBextractor(**cfg)
+    except pkg.OrbError as err:
+        log("extract cfg rejected by the library: %s %s" % (cfg, err))
+        return True
+    try:
+        o = oracle.OracleExtractor(**cfg)
+        try:
+            mono, kps, desc = e(img, None, lap)
+        except (pkg.OrbError, ValueError) as err:   # documented limits of orbx_configure (include/orbhip.h): refused loudly, never wrong
+            log("extract refused: %s %dx%d: %s" % (cfg, W, H, err))
+            return True
+        mono_r, kps_r, desc_r = o.extract(img, lap)
+        ok = mono == mono_r and len(kps) == len(kps_r)
+        if ok:
+            for f in ("x", "y", "size", "angle", "response", "octave"):
+                ok = ok and np.array_equal(kps[f], kps_r[f])
+            ok = ok and np.array_equal(desc, desc_r)
+        if not ok:
+            log("EXTRACT MISMATCH cfg=%s size=%dx%d lap=%s n=%d/%d mono=%s/%s" % (cfg, W, H, lap, len(kps), len(kps_r), mono, mono_r))
+        return ok
+    finally:
+        e.close()
+
+
+def fuzz_match(pkg, oracle, synth, rng, log, cache):
+    if "frames" not in cache:
+        frames, offs = synth.make_stream(77, 2)
+        o = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+        cache["frames"] = [o.extract(f)[1:] for f in frames]
+        cache["sf"] = o.scale_factors
+        cache["offs"] = offs
+    (k0, d0), (k1, d1) = cache["frames"]
+    sf, offs = cache["sf"], cache["offs"]
+    nc = int(rng.integers(1, len(k1) + 1))
+    sel = np.sort(rng.choice(len(k1), nc, replace=False))
+    kc, dc = k1[sel], d1[sel]
+    nq = int(rng.integers(1, len(k0) + 1))
+    qs = rng.choice(len(k0), nq, replace=rng.random() < 0.3)      # repeated queries: claims and ties
+    kq, dq = k0[qs], d0[qs].copy()
+    if rng.random() < 0.3:                                        # corrupt some descriptors: ratio test and TH_HIGH edges
+        flip = rng.random(dq.shape) < 0.02
+        dq ^= flip.astype(np.uint8) * rng.integers(1, 256, dq.shape, dtype=np.uint8)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    F = pkg.FrameView(kc, dc, bounds)
+    OF = oracle.OracleFrame(kc["x"], kc["y"], kc["octave"], kc["angle"], dc, bounds, sf)
+    u = (kq["x"] + np.float32(offs[0][0] - offs[1][0]) + rng.normal(0, 2, nq)).astype(np.float32)
+    v = (kq["y"] + np.float32(offs[0][1] - offs[1][1]) + rng.normal(0, 2, nq)).astype(np.float32)
+    radius = rng.choice(np.array([0.5, 3, 7, 15, 40, 200, 1e4], np.float32), nq).astype(np.float32)
+    lvl = kq["octave"].astype(np.int32)
+    mode = rng.integers(0, 3)
+    minl = lvl - 1 if mode == 0 else (np.full(nq, -1, np.int32) if mode == 1 else lvl)
+    maxl = lvl + 1 if mode == 0 else (np.full(nq, -1, np.int32) if mode == 1 else lvl)
+    occupied = rng.random(nc) < rng.choice([0.0, 0.1, 0.5])
+    obs_occ = rng.random(nc) < 0.7
+    qobs = (rng.random(nq) < rng.choice([1.0, 0.8, 0.3])).astype(np.uint8)
+    in_view = (rng.random(nq) < 0.9).astype(np.uint8)
+    nnratio = float(rng.choice([0.6, 0.75, 0.8, 0.9, 1.0]))
+    th = int(rng.choice([30, 50, 100, 255]))   # 256 would accept "no candidate" (bestDist starts at 256): undefined in the reference
+    second = bool(rng.integers(0, 2))
+    for X in (F, OF):
+        X.slot[:] = np.where(occupied, 1 << 20, -1)
+        X.slot_obs[:] = (occupied & obs_occ).astype(np.uint8)
+    m = cache.setdefault("matcher", pkg.ORBmatcher(0.8, True))
+    flags = (in_view | (qobs << 1)).astype(np.uint8)
+    n_gpu, moq_gpu, bd_gpu = m.search_window(F, dq, u, v, radius, minl, maxl, flags=flags, nnratio=nnratio, th_dist=th, use_second=second)
+    n_ref, moq_ref, bd_ref = OF.search_by_projection_win(dq, u, v, radius, minl, maxl, nnratio, th, second, qobs=qobs, in_view=in_view)
+    ok = n_gpu == n_ref and np.array_equal(moq_gpu, moq_ref) and np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+    if not ok:
+        log("MATCH MISMATCH nq=%d nc=%d mode=%d nnratio=%s th=%d second=%s n=%d/%d" % (nq, nc, mode, nnratio, th, second, n_gpu, n_ref))
+    return ok
+
+
+def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), first=0, verbose=False):
+    """Cases first .. first+n-1 of stream `seed`; every case draws from its own generator, so one case can be replayed alone."""
+    bad, cache, t0 = 0, {}, time.time()
+    try:
+        for i in range(first, first + n):
+            if verbose:
+                log("case %d" % i)
+            ok1 = fuzz_extract(pkg, oracle, synth, np.random.default_rng([seed, i, 0]), log)
+            ok2 = fuzz_match(pkg, oracle, synth, np.random.default_rng([seed, i, 1]), log, cache)
+            if not (ok1 and ok2):
+                log("   ^ case %d of seed %d" % (i, seed))
+            bad += (not ok1) + (not ok2)
+            if (i + 1 - first) % 20 == 0:
+                log("%d / %d cases, %d mismatches, %.0f s" % (i + 1 - first, n, bad, time.time() - t0))
+    finally:
+        if "matcher" in cache:
+            cache["matcher"].close()
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
+    synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
+    from oracle import oracle_py as oracle   # the checker
+    bad = run(pkg, oracle, synth, args.n, args.seed, first=args.first, verbose=args.verbose)
+    print("fuzz: %d extractor + %d matcher cases, %d mismatches" % (args.n, args.n, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
