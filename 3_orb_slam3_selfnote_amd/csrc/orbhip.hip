@@ -27,6 +27,8 @@ namespace {
 inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: round-half-even
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#define PROF_DEPTH 32   // batches whose stage events are kept for orbx_get_stage_ms / orbm_get_stage_ms (averaged)
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -88,7 +90,8 @@ struct orbx_handle {
   bool graph_ok = true;   // cleared (for good) if capture / instantiation fails: the plain path is used instead
   // profiling
   bool profiling = false;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[PROF_DEPTH][6] = {};   // ring of event sets: one per batch since profiling was switched on
+  int prof_head = 0;                   // batches recorded since then
   bool ev_ok = false;
   float stage_ms[5] = {0, 0, 0, 0, 0};
   bool stage_valid = false;
@@ -198,7 +201,8 @@ void orbx_destroy(orbx_t *h) {
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->ev_ok)
-    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    for (auto &set : h->ev)
+      for (auto &e : set) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -427,22 +431,30 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
 void orbx_set_profiling(orbx_t *h, int enable) {
   if (!h) return;
   h->profiling = enable != 0;
+  h->prof_head = 0;
+  h->stage_valid = false;
   if (h->profiling && !h->ev_ok) {
     (void)hipSetDevice(h->device);
     bool ok = true;
-    for (auto &e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto &set : h->ev)
+      for (auto &e : set) ok = ok && hipEventCreate(&e) == hipSuccess;
     h->ev_ok = ok;
   }
 }
 
+// Average per stage over the batches launched since profiling was switched on (the PROF_DEPTH most recent ones).
 int orbx_get_stage_ms(orbx_t *h, float *ms, int cap) {
-  if (!h || !ms || !h->profiling || !h->ev_ok || !h->stage_valid) return 0;
-  if (hipEventSynchronize(h->ev[5]) != hipSuccess) return 0;
-  int n = std::min(cap, 5);
-  for (int i = 0; i < n; i++) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]) != hipSuccess) t = -1.f;
-    ms[i] = t;
+  if (!h || !ms || !h->profiling || !h->ev_ok || !h->stage_valid || h->prof_head <= 0) return 0;
+  const int nb = std::min(h->prof_head, PROF_DEPTH), n = std::min(cap, 5);
+  if (hipEventSynchronize(h->ev[(h->prof_head - 1) % PROF_DEPTH][5]) != hipSuccess) return 0;
+  for (int i = 0; i < n; i++) ms[i] = 0.f;
+  for (int b = 0; b < nb; b++) {
+    const int slot = (h->prof_head - 1 - b) % PROF_DEPTH;
+    for (int i = 0; i < n; i++) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, h->ev[slot][i], h->ev[slot][i + 1]) != hipSuccess) return 0;
+      ms[i] += t / (float)nb;
+    }
   }
   return n;
 }
@@ -496,8 +508,8 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   P.out_counts = d_counts;
   P.cap = cap;
   const bool prof = h->profiling && h->ev_ok;
-  h->stage_valid = false;
-  if (prof) XCHECK(h, hipEventRecord(h->ev[0], s));
+  hipEvent_t *pev = h->ev[h->prof_head % PROF_DEPTH];
+  if (prof) XCHECK(h, hipEventRecord(pev[0], s));
   for (int l = 1; l < h->nlevels; l++) {
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
@@ -505,17 +517,17 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     if (lds > 48 * 1024) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
   }
-  if (prof) XCHECK(h, hipEventRecord(h->ev[1], s));
+  if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
-  if (prof) XCHECK(h, hipEventRecord(h->ev[2], s));
+  if (prof) XCHECK(h, hipEventRecord(pev[2], s));
   if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
   else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
-  if (prof) XCHECK(h, hipEventRecord(h->ev[3], s));
+  if (prof) XCHECK(h, hipEventRecord(pev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
-  if (prof) XCHECK(h, hipEventRecord(h->ev[4], s));
+  if (prof) XCHECK(h, hipEventRecord(pev[4], s));
   hipLaunchKernelGGL(k_describe, dim3(((h->totalKp + 3) / 4) * nframes), dim3(256), 0, s, P);
   hipLaunchKernelGGL(k_counts, dim3((nframes + 63) / 64), dim3(64), 0, s, P);
-  if (prof) { XCHECK(h, hipEventRecord(h->ev[5], s)); h->stage_valid = true; }
+  if (prof) { XCHECK(h, hipEventRecord(pev[5], s)); h->prof_head++; h->stage_valid = true; }
   XCHECK(h, hipGetLastError());
   h->last = P;
   h->have_last = true;
@@ -812,7 +824,8 @@ struct orbm_handle {
   // orbm_search_by_projection_batch_device): device pointers
   struct { int nleft = 0; const int32_t *partner = nullptr; const uint8_t *qside = nullptr; int couple = 0; int serial = 0; uint8_t *qany = nullptr; int init_th_low = -1; const float *fuse_inv_sigma2 = nullptr; } ext;
   bool profiling = false;
-  hipEvent_t ev[3] = {};
+  hipEvent_t ev[PROF_DEPTH][3] = {};
+  int prof_head = 0;
   bool ev_ok = false, ms_valid = false;
   std::string err;
 };
@@ -851,7 +864,9 @@ void orbm_destroy(orbm_t *m) {
                     &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block};
   for (DevBuf *b : bufs) b->release();
   if (m->pin) (void)hipHostFree(m->pin);
-  if (m->ev_ok) { (void)hipEventDestroy(m->ev[0]); (void)hipEventDestroy(m->ev[1]); (void)hipEventDestroy(m->ev[2]); }
+  if (m->ev_ok)
+    for (auto &set : m->ev)
+      for (auto &e : set) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -861,25 +876,39 @@ const char *orbm_last_error(const orbm_t *m) { return m ? m->err.c_str() : "null
 void orbm_set_profiling(orbm_t *m, int enable) {
   if (!m) return;
   m->profiling = enable != 0;
+  m->prof_head = 0;
+  m->ms_valid = false;
   if (m->profiling && !m->ev_ok) {
     (void)hipSetDevice(m->device);
-    m->ev_ok = hipEventCreate(&m->ev[0]) == hipSuccess && hipEventCreate(&m->ev[1]) == hipSuccess && hipEventCreate(&m->ev[2]) == hipSuccess;
+    bool ok = true;
+    for (auto &set : m->ev)
+      for (auto &e : set) ok = ok && hipEventCreate(&e) == hipSuccess;
+    m->ev_ok = ok;
   }
 }
 
 float orbm_get_last_ms(orbm_t *m) {
-  if (!m || !m->profiling || !m->ev_ok || !m->ms_valid) return -1.f;
+  if (!m || !m->profiling || !m->ev_ok || !m->ms_valid || m->prof_head <= 0) return -1.f;
   float t = -1.f;
-  if (hipEventSynchronize(m->ev[2]) != hipSuccess) return -1.f;
-  if (hipEventElapsedTime(&t, m->ev[0], m->ev[2]) != hipSuccess) return -1.f;
+  hipEvent_t *e = m->ev[(m->prof_head - 1) % PROF_DEPTH];
+  if (hipEventSynchronize(e[2]) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&t, e[0], e[2]) != hipSuccess) return -1.f;
   return t;
 }
 
+// {scan, resolve} averaged over the searches launched since profiling was switched on (the PROF_DEPTH most recent ones).
 int orbm_get_stage_ms(orbm_t *m, float *ms, int cap) {
-  if (!m || !ms || cap < 2 || !m->profiling || !m->ev_ok || !m->ms_valid) return 0;
-  if (hipEventSynchronize(m->ev[2]) != hipSuccess) return 0;
-  if (hipEventElapsedTime(&ms[0], m->ev[0], m->ev[1]) != hipSuccess) return 0;
-  if (hipEventElapsedTime(&ms[1], m->ev[1], m->ev[2]) != hipSuccess) return 0;
+  if (!m || !ms || cap < 2 || !m->profiling || !m->ev_ok || !m->ms_valid || m->prof_head <= 0) return 0;
+  const int nb = std::min(m->prof_head, PROF_DEPTH);
+  if (hipEventSynchronize(m->ev[(m->prof_head - 1) % PROF_DEPTH][2]) != hipSuccess) return 0;
+  ms[0] = ms[1] = 0.f;
+  for (int b = 0; b < nb; b++) {
+    hipEvent_t *e = m->ev[(m->prof_head - 1 - b) % PROF_DEPTH];
+    float t0 = 0, t1 = 0;
+    if (hipEventElapsedTime(&t0, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&t1, e[1], e[2]) != hipSuccess) return 0;
+    ms[0] += t0 / (float)nb;
+    ms[1] += t1 / (float)nb;
+  }
   return 2;
 }
 
@@ -1015,8 +1044,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     MCHECK(m, m->d_topk.reserve(need));
   }
   const bool prof = m->profiling && m->ev_ok;
-  m->ms_valid = false;
-  if (prof) MCHECK(m, hipEventRecord(m->ev[0], s));
+  hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
+  if (prof) MCHECK(m, hipEventRecord(pev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16); see k_match_resolve
   const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
@@ -1033,7 +1062,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);  \
     else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);     \
     else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                 \
-    if (prof) MCHECK(m, hipEventRecord(m->ev[1], s));                                                                     \
+    if (prof) MCHECK(m, hipEventRecord(pev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
     else                                                                                                                  \
@@ -1042,7 +1071,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
   else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
 #undef LAUNCH_MATCH
-  if (prof) { MCHECK(m, hipEventRecord(m->ev[2], s)); m->ms_valid = true; }
+  if (prof) { MCHECK(m, hipEventRecord(pev[2], s)); m->prof_head++; m->ms_valid = true; }
   MCHECK(m, hipGetLastError());
   return 0;
 }

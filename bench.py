@@ -176,6 +176,11 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # HIP events inside liborbhip, on each pipeline's own launch stream, around every kernel of every timed step (a ring of
+    # event sets per handle): the per-kernel averages below are measured over the timed region itself.
+    for pp in pipes:
+        pp.ex.set_profiling(True)
+        pp.mt.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -192,36 +197,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- per-kernel timing pass: HIP events recorded inside liborbhip on each pipeline's own launch stream, in the SAME
-    # regime as the timed region (all pipelines in flight), so the averages agree with rocprofv3 --kernel-trace --stats
-    # of this command.  With several streams a kernel's duration includes the time it shares the chip with the others.
+    acc, nsamp = {}, 0
     for pp in pipes:
-        pp.ex.set_profiling(True)
-        pp.mt.set_profiling(True)
-    acc = {}
-    nprof, nsamp = 6, 0
-    for _ in range(nprof):
-        for pp in pipes:
-            pp.step()
-        torch.cuda.synchronize()
-        for pp in pipes:
-            st = pp.ex.stage_ms()
-            if not args.no_match:
-                st.update(pp.mt.stage_ms())
-            for k, v in st.items():
-                acc[k] = acc.get(k, 0.0) + v
-            nsamp += 1
+        st = pp.ex.stage_ms()
+        if not st:
+            continue                      # a pipeline that got no step (steps < streams)
+        if not args.no_match:
+            st.update(pp.mt.stage_ms())
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0.0) + v
+        nsamp += 1
     acc = {k: v / nsamp for k, v in acc.items()}
     # the same kernels alone on the chip (one pipeline, synchronised between steps): isolates kernel quality from sharing
-    iso = {}
+    pipes[0].ex.set_profiling(True)       # resets the event ring
+    pipes[0].mt.set_profiling(True)
     for _ in range(4):
         pipes[0].step()
         torch.cuda.synchronize()
-        st = pipes[0].ex.stage_ms()
-        if not args.no_match:
-            st.update(pipes[0].mt.stage_ms())
-        for k, v in st.items():
-            iso[k] = iso.get(k, 0.0) + v / 4
+    iso = pipes[0].ex.stage_ms()
+    if not args.no_match:
+        iso.update(pipes[0].mt.stage_ms())
     for pp in pipes:
         pp.ex.set_profiling(False)
         pp.mt.set_profiling(False)

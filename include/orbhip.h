@@ -99,8 +99,10 @@ int orbx_download_candidates(orbx_t *h, int frame, int level, float *xyr, int ca
 /* DistributeOctTree output of one level (ORBextractor.cc:859-860), list order, same coordinates. */
 int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, int cap);
 
-/* Per-stage GPU time of the last extract call, measured with HIP events recorded on the stream the kernels were
- * launched on.  Enable with orbx_set_profiling(h, 1).  Stages: 0 pyramid, 1 fast, 2 octree, 3 blur,
+/* Per-stage GPU time, measured with HIP events recorded on the stream the kernels were launched on.
+ * orbx_set_profiling(h, 1) starts (or restarts) a recording; every extract call after it records one event set into a ring of
+ * 32, and orbx_get_stage_ms returns the per-stage AVERAGE over the calls recorded since then (the 32 most recent): one
+ * call = "the last call", a whole timed region = its average.  Stages: 0 pyramid, 1 fast, 2 octree, 3 blur,
  * 4 orient+describe.  Returns the number of stages written (ms). */
 void orbx_set_profiling(orbx_t *h, int enable);
 int orbx_get_stage_ms(orbx_t *h, float *ms, int cap);
@@ -418,7 +420,8 @@ void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int n
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */
 void orbm_set_profiling(orbm_t *m, int enable);
 float orbm_get_last_ms(orbm_t *m);
-/* Per-kernel split of the same: ms[0] = k_match_scan, ms[1] = k_match_resolve.  Returns 2, or 0 if unavailable. */
+/* Per-kernel split, averaged over the searches launched since orbm_set_profiling(m, 1) (ring of 32 event sets, as for
+ * orbx_get_stage_ms): ms[0] = k_match_scan, ms[1] = k_match_resolve.  Returns 2, or 0 if unavailable. */
 int orbm_get_stage_ms(orbm_t *m, float *ms, int cap);
 
 #ifdef __cplusplus
