@@ -92,12 +92,13 @@ def main():
     # one process per GPU; backend "nccl" (= RCCL) for the barrier / MAX-time all-reduce.  ORB_BENCH_BACKEND=gloo lets several
     # ranks rehearse the N>1 path on a box with fewer GPUs (ranks then share devices modulo the device count).
     backend = os.environ.get("ORB_BENCH_BACKEND", "nccl")
+    if world > 1:   # before anything initialises the GPU runtime: the host driver only supports dmabuf IPC
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
