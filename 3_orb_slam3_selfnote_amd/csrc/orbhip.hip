@@ -914,6 +914,7 @@ int orbm_get_stage_ms(orbm_t *m, float *ms, int cap) {
 
 // ORBmatcher.cc:2463-2483 (the bit trick there computes exactly popcount)
 int orbm_descriptor_distance(const uint8_t *a, const uint8_t *b) {
+  if (!a || !b) return ORBX_E_ARG;
   int dist = 0;
   for (int i = 0; i < 8; i++) {
     uint32_t pa, pb;
@@ -925,8 +926,10 @@ int orbm_descriptor_distance(const uint8_t *a, const uint8_t *b) {
 }
 
 void orbm_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3) {  // ORBmatcher.cc:2416-2458
+  if (!ind1 || !ind2 || !ind3) return;
   int max1 = 0, max2 = 0, max3 = 0;
   *ind1 = *ind2 = *ind3 = -1;
+  if (!histo) return;
   for (int i = 0; i < L; i++) {
     const int s = histo[i];
     if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
@@ -958,6 +961,7 @@ static void undistort_one(double u, double v, const float *K, const float *D, in
 }
 
 void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K, const float *D, int nD, orbx_keypoint_t *keys_un) {
+  if (!keys || !keys_un || !K || !D) return;
   for (int i = 0; i < n; i++) {
     orbx_keypoint_t k = keys[i];
     if (D[0] != 0.0f) undistort_one((double)keys[i].x, (double)keys[i].y, K, D, nD, &k.x, &k.y);
@@ -966,6 +970,7 @@ void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K
 }
 
 void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *min_x, float *max_x, float *min_y, float *max_y) {
+  if (!K || !D || !min_x || !max_x || !min_y || !max_y) return;
   if (D[0] != 0.0f) {
     const float c[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
     float o[4][2];
@@ -980,6 +985,7 @@ void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int n
 }
 
 void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float *u, float *v) {
+  if (!p || !u || !v) return;
   if (cam_type == 0) {  // Pinhole.cpp:46-49
     *u = p[0] * X / Z + p[2];
     *v = p[1] * Y / Z + p[3];

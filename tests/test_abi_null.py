@@ -1,0 +1,32 @@
+"""Every C-ABI entry point survives an all-zero / all-NULL call: it returns an error code (or does nothing), it does not crash.
+Runs without a GPU: a NULL handle or NULL buffers are rejected before any device work."""
+import importlib
+import subprocess
+import sys
+import textwrap
+
+
+def test_null_arguments_do_not_crash():
+    code = textwrap.dedent('''
+        import ctypes as C, importlib, sys
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
+        L = pkg.load()
+        for name in pkg.ABI_SYMBOLS:
+            fn = getattr(L, name)
+            assert fn.argtypes is not None, name
+            args = []
+            for t in fn.argtypes:
+                if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+                    args.append(None)
+                elif t in (C.c_float, C.c_double):
+                    args.append(0.0)
+                else:
+                    args.append(0)
+            print(name, flush=True)
+            fn(*args)
+        print("SWEEP-DONE", flush=True)
+    ''') % importlib.import_module("conftest").ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "(nothing)"
+    assert p.returncode == 0 and last == "SWEEP-DONE", "crashed in %s (rc %d)\n%s" % (last, p.returncode, p.stderr[-2000:])
