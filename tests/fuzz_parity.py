@@ -34,7 +34,7 @@ def random_image(rng, H, W, synth):
     return img
 
 
-def fuzz_extract(pkg, oracle, synth, rng, log):
+def fuzz_extract(pkg, oracle, synth, rng, log, cache):
     H, W = int(rng.integers(96, 640)), int(rng.integers(96, 800))
     cfg = dict(nfeatures=int(rng.choice([30, 200, 500, 1000, 1500, 3000])), scaleFactor=float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0])),
                nlevels=int(rng.integers(1, 9)), iniThFAST=int(rng.integers(8, 41)), minThFAST=int(rng.integers(2, 12)))
@@ -55,6 +55,7 @@ def fuzz_extract(pkg, oracle, synth, rng, log):
             log("extract refused: %s %dx%d: %s" % (cfg, W, H, err))
             return True
         mono_r, kps_r, desc_r = o.extract(img, lap)
+        cache.setdefault("stats", {}).setdefault("keypoints", []).append(len(kps_r))
         ok = mono == mono_r and len(kps) == len(kps_r)
         if ok:
             for f in ("x", "y", "size", "angle", "response", "octave"):
@@ -109,9 +110,57 @@ def fuzz_match(pkg, oracle, synth, rng, log, cache):
     flags = (in_view | (qobs << 1)).astype(np.uint8)
     n_gpu, moq_gpu, bd_gpu = m.search_window(F, dq, u, v, radius, minl, maxl, flags=flags, nnratio=nnratio, th_dist=th, use_second=second)
     n_ref, moq_ref, bd_ref = OF.search_by_projection_win(dq, u, v, radius, minl, maxl, nnratio, th, second, qobs=qobs, in_view=in_view)
+    cache.setdefault("stats", {}).setdefault("window_matches", []).append(n_ref)
     ok = n_gpu == n_ref and np.array_equal(moq_gpu, moq_ref) and np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
     if not ok:
         log("MATCH MISMATCH nq=%d nc=%d mode=%d nnratio=%s th=%d second=%s n=%d/%d" % (nq, nc, mode, nnratio, th, second, n_gpu, n_ref))
+    return ok
+
+
+def fuzz_last_frame(pkg, oracle, synth, rng, log, cache):
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:2027-2289): random pose, depths, camera model, stereo."""
+    if "frames" not in cache:
+        fuzz_match(pkg, oracle, synth, np.random.default_rng(0), log, cache)
+    (k0, d0), (k1, d1) = cache["frames"]
+    sf, offs = cache["sf"], cache["offs"]
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    n0 = len(k0)
+    z = rng.uniform(1.5, 20.0, n0).astype(np.float32)
+    Xw = np.stack([(k0["x"] - np.float32(cx)) / np.float32(fx) * z, (k0["y"] - np.float32(cy)) / np.float32(fy) * z, z], axis=1).astype(np.float32)
+    Xw[rng.random(n0) < 0.03, 2] = -1.0
+    ax = rng.normal(0, 1, 3); ax /= np.linalg.norm(ax)
+    ang = rng.normal(0, 0.004)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = R.astype(np.float32)
+    dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+    stereo = bool(rng.integers(0, 2))
+    Tcw[:3, 3] = [dx * 5.0 / fx + rng.normal(0, 0.01), dy * 5.0 / fy + rng.normal(0, 0.01), rng.choice([0.0, -0.3, 0.3]) if stereo else rng.normal(0, 0.05)]
+    Tlw = np.eye(4, dtype=np.float32)
+    has_mp = (rng.random(n0) < 0.8).astype(np.uint8)
+    obs = (rng.random(n0) < 0.9).astype(np.uint8)
+    cam = int(rng.integers(0, 2))
+    if cam == 0:
+        params = np.array([fx, fy, cx, cy], np.float32)
+    else:
+        params = np.array([190.978477 * 2, 190.973307 * 2, 376.0, 240.0, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736], np.float32)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(k1)) < 0.7, k1["x"] - np.float32(47.9) / np.float32(5.0), np.float32(-1)).astype(np.float32)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    th = float(rng.choice([7.0, 15.0, 30.0]))
+    F = pkg.FrameView(k1, d1, bounds, u_right=u_right)
+    OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf, u_right=u_right)
+    mb, mbf = (0.11, 47.9) if stereo else (0.0, 0.0)
+    m = cache.setdefault("matcher", pkg.ORBmatcher(0.8, True))
+    n_gpu = m.SearchByProjectionLastFrame(F, sf, has_mp, Xw, d0, k0, Tcw, Tlw, cam, params, th, bMono=not stereo, mb=mb, mbf=mbf, mp_obs=obs)
+    n_ref = OF.search_by_projection_ff(has_mp, Xw, d0, k0["octave"], k0["angle"], Tcw, Tlw, cam, params, th, mono=not stereo,
+                                       check_ori=True, mb=mb, mbf=mbf, qobs=obs)
+    cache.setdefault("stats", {}).setdefault("last_frame_matches", []).append(n_ref)
+    ok = n_gpu == n_ref and np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
+    if not ok:
+        log("LAST-FRAME MISMATCH cam=%d stereo=%s th=%s n=%d/%d" % (cam, stereo, th, n_gpu, n_ref))
     return ok
 
 
@@ -122,16 +171,19 @@ def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), fir
         for i in range(first, first + n):
             if verbose:
                 log("case %d" % i)
-            ok1 = fuzz_extract(pkg, oracle, synth, np.random.default_rng([seed, i, 0]), log)
+            ok1 = fuzz_extract(pkg, oracle, synth, np.random.default_rng([seed, i, 0]), log, cache)
             ok2 = fuzz_match(pkg, oracle, synth, np.random.default_rng([seed, i, 1]), log, cache)
-            if not (ok1 and ok2):
+            ok3 = fuzz_last_frame(pkg, oracle, synth, np.random.default_rng([seed, i, 2]), log, cache)
+            if not (ok1 and ok2 and ok3):
                 log("   ^ case %d of seed %d" % (i, seed))
-            bad += (not ok1) + (not ok2)
+            bad += (not ok1) + (not ok2) + (not ok3)
             if (i + 1 - first) % 20 == 0:
                 log("%d / %d cases, %d mismatches, %.0f s" % (i + 1 - first, n, bad, time.time() - t0))
     finally:
         if "matcher" in cache:
             cache["matcher"].close()
+    for k, v in cache.get("stats", {}).items():
+        log("   %s: %d cases, mean %.0f, min %d, max %d" % (k, len(v), np.mean(v), min(v), max(v)))
     return bad
 
 
@@ -146,7 +198,7 @@ def main():
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
     from oracle import oracle_py as oracle   # the checker
     bad = run(pkg, oracle, synth, args.n, args.seed, first=args.first, verbose=args.verbose)
-    print("fuzz: %d extractor + %d matcher cases, %d mismatches" % (args.n, args.n, bad))
+    print("fuzz: %d extractor + %d window-search + %d last-frame cases, %d mismatches" % (args.n, args.n, args.n, bad))
     sys.exit(1 if bad else 0)
 
 
