@@ -283,3 +283,19 @@ def test_cvt_color_gray(pkg, ex, ch, rgb):
         assert np.array_equal(ex.cvtColorGray(im, rgb), ref)
     white = np.full((8, 8, ch), 255, np.uint8)
     assert (ex.cvtColorGray(white, rgb) == 255).all()
+
+
+def test_blur_saturation_and_borders(ex, oex, oracle):
+    """cv::GaussianBlur's 8-bit fixed point reaches 257 on saturated areas (the taps sum to 257/256) and is clamped; white and
+    black blocks up to the image border exercise the clamp in the packed store and the reflected borders on every level."""
+    H, W = 480, 752
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (((yy // 37 + xx // 41) % 2) * 255).astype(np.uint8)
+    img[:5, :] = 255; img[:, -6:] = 255; img[-3:, :] = 254; img[:, :2] = 1
+    ex(img, None, (0, 0))
+    pyr = oex.pyramid(img)
+    for l in range(8):
+        assert np.array_equal(ex.image_pyramid_level(l), pyr[l]), "pyramid level %d" % l
+        ref = oracle.gaussian_blur7(pyr[l])
+        assert np.array_equal(ex.blurred_level(l), ref), "blur level %d" % l
+    assert (oracle.gaussian_blur7(pyr[0]) == 255).any()
