@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
         const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
         const int r0 = S0[sx] * a0 + S0[sx1] * a1;
         const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
+        // no saturate_cast needed: the coefficients are non-negative and each pair sums to 2048, so v is a convex
+        // combination of four bytes, rounded down-ish: always inside [0, 255]
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
         packed |= (uint32_t)v << (8 * j);
       }
       uint8_t *dst = dstplane + mul24((uint32_t)dy, (uint32_t)G.pitch);
