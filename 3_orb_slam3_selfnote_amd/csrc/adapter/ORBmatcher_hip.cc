@@ -318,10 +318,11 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
 }
 
 int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) {
-  if (pKF1->NLeft != -1 || pKF2->NLeft != -1) return SearchByBoW_ref(pKF1, pKF2, vpMatches12);  // two-camera rigs: reference path
+  // Two-camera rigs: the reference skips every index >= mvKeysUn.size(), i.e. the right image's keypoints (:874-876, :894-896);
+  // clearing has_mappoint for them has the same effect (`if(!pMP) continue`, :879 / :900).
   const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
   vpMatches12.assign(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));  // :852
-  struct Flat { std::vector<uint8_t> has; std::vector<uint32_t> id; std::vector<int32_t> start, idx; orbm_keyframe_t k; };
+  struct Flat { std::vector<uint8_t> has; std::vector<uint32_t> id; std::vector<int32_t> start, idx; std::vector<cv::KeyPoint> keys; orbm_keyframe_t k; };
   auto flatten = [](KeyFrame *pKF, const std::vector<MapPoint *> &mps, Flat &X) {
     X.start.push_back(0);
     for (DBoW2::FeatureVector::const_iterator it = pKF->mFeatVec.begin(); it != pKF->mFeatVec.end(); ++it) {
@@ -329,9 +330,12 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
       for (unsigned v : it->second) X.idx.push_back((int32_t)v);
       X.start.push_back((int32_t)X.idx.size());
     }
+    const int nUn = (int)pKF->mvKeysUn.size();
     X.has.resize(pKF->N);
-    for (int i = 0; i < pKF->N; i++) X.has[i] = mps[i] && !mps[i]->isBad();
-    X.k.n = pKF->N; X.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(pKF->mvKeysUn.data());
+    for (int i = 0; i < pKF->N; i++) X.has[i] = (pKF->NLeft == -1 || i < nUn) && mps[i] && !mps[i]->isBad();
+    X.keys = pKF->mvKeysUn;
+    X.keys.resize(pKF->N);   // rigs: N counts both images, the padding is never read (has_mappoint = 0 there)
+    X.k.n = pKF->N; X.k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(X.keys.data());
     X.k.descriptors = pKF->mDescriptors.data; X.k.has_mappoint = X.has.data();
     X.k.n_nodes = (int32_t)X.id.size();
     X.k.node_id = X.id.data(); X.k.node_start = X.start.data(); X.k.node_idx = X.idx.data();
