@@ -68,6 +68,29 @@ def fuzz_extract(pkg, oracle, synth, rng, log, cache):
         e.close()
 
 
+def fuzz_reuse(pkg, oracle, synth, rng, log, cache):
+    """One long-lived extractor handle fed images of changing size: workspace re-sizing and re-capture of the per-frame hipGraph."""
+    if "reuse" not in cache:
+        cache["reuse"] = (pkg.ORBextractor(700, 1.2, 8, 20, 7), oracle.OracleExtractor(700, 1.2, 8, 20, 7))
+    e, o = cache["reuse"]
+    H, W = int(rng.integers(120, 500)), int(rng.integers(160, 760))
+    img = random_image(rng, H, W, synth)
+    lap = (0, 0) if rng.random() < 0.5 else (int(W * 0.25), int(W * 0.6))
+    try:
+        mono, kps, desc = e(img, None, lap)
+    except (pkg.OrbError, ValueError) as err:
+        log("reuse refused %dx%d: %s" % (W, H, err))
+        return True
+    mono_r, kps_r, desc_r = o.extract(img, lap)
+    ok = mono == mono_r and len(kps) == len(kps_r) and np.array_equal(desc, desc_r)
+    if ok:
+        for f in ("x", "y", "angle", "response", "octave"):
+            ok = ok and np.array_equal(kps[f], kps_r[f])
+    if not ok:
+        log("REUSE MISMATCH size=%dx%d lap=%s n=%d/%d" % (W, H, lap, len(kps), len(kps_r)))
+    return ok
+
+
 def fuzz_match(pkg, oracle, synth, rng, log, cache):
     if "frames" not in cache:
         frames, offs = synth.make_stream(77, 2)
@@ -174,14 +197,17 @@ def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), fir
             ok1 = fuzz_extract(pkg, oracle, synth, np.random.default_rng([seed, i, 0]), log, cache)
             ok2 = fuzz_match(pkg, oracle, synth, np.random.default_rng([seed, i, 1]), log, cache)
             ok3 = fuzz_last_frame(pkg, oracle, synth, np.random.default_rng([seed, i, 2]), log, cache)
-            if not (ok1 and ok2 and ok3):
+            ok4 = fuzz_reuse(pkg, oracle, synth, np.random.default_rng([seed, i, 3]), log, cache)
+            if not (ok1 and ok2 and ok3 and ok4):
                 log("   ^ case %d of seed %d" % (i, seed))
-            bad += (not ok1) + (not ok2) + (not ok3)
+            bad += (not ok1) + (not ok2) + (not ok3) + (not ok4)
             if (i + 1 - first) % 20 == 0:
                 log("%d / %d cases, %d mismatches, %.0f s" % (i + 1 - first, n, bad, time.time() - t0))
     finally:
         if "matcher" in cache:
             cache["matcher"].close()
+        if "reuse" in cache:
+            cache["reuse"][0].close()
     for k, v in cache.get("stats", {}).items():
         log("   %s: %d cases, mean %.0f, min %d, max %d" % (k, len(v), np.mean(v), min(v), max(v)))
     return bad
@@ -198,7 +224,7 @@ def main():
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
     from oracle import oracle_py as oracle   # the checker
     bad = run(pkg, oracle, synth, args.n, args.seed, first=args.first, verbose=args.verbose)
-    print("fuzz: %d extractor + %d window-search + %d last-frame cases, %d mismatches" % (args.n, args.n, args.n, bad))
+    print("fuzz: %d cases each of: extractor configuration, window search, last-frame search, handle reuse; %d mismatches" % (args.n, bad))
     sys.exit(1 if bad else 0)
 
 
