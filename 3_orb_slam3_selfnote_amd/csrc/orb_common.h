@@ -10,8 +10,10 @@
 #define ORB_DISC_PIXELS 749    // pixels of the radius-15 disc given by umax (ORBextractor.cc:452-467)
 #define ORB_MAXL 16
 
-// FAST cell tile in LDS: interior <= 59x59 (wCell = ceil(width/floor(width/30)) < 60), +3 px ring.
-#define FAST_TILE_PITCH 72
+// FAST cell tile in LDS: interior <= 59x59 (wCell = ceil(width/floor(width/30)) < 60), +3 px ring.  The pitch is five
+// 16-byte chunks: the tile is filled by global_load_lds_dwordx4, whose LDS image is lane-linear (no padding between rows).
+#define FAST_TILE_PITCH 80
+#define FAST_TILE_COLS 65      // widest cell window (interior 59 + 6)
 #define FAST_TILE_ROWS 66
 #define FAST_S_PITCH 64  // score plane incl. 1-px zero ring: <= 61 columns
 

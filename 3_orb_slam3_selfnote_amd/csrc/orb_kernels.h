@@ -305,7 +305,7 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
 #ifndef FAST_NT
 #define FAST_NT 256
 #endif
-#define FAST_LIST_SEG 900   // list entries per wavefront: 15 rows x 60 columns (64-lane rows), 16 rows x 32 (32-lane rows)
+#define FAST_LIST_SEG 888   // list entries per wavefront: 15 rows x 59 columns (64-lane rows), 16 rows x 32 (32-lane rows)
 static_assert(FAST_NT == 256, "k_fast's list segments assume four wavefronts");
 // Diagnostic builds (-DFAST_STAMPS, tools/fast_stamps.py): cycles per section, thread 0 of every workgroup.
 #ifdef FAST_STAMPS
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[4 * FAST_LIST_SEG];
-  __shared__ uint32_t sKept[1024];
+  __shared__ uint32_t sKept[900];   // strict 3x3 maxima: at most ceil(cw/2) * ceil(ch/2) <= 30 * 30
   __shared__ uint32_t sCount, sNKept, sNOut;
   __shared__ __align__(16) uint32_t sWCount[4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -348,16 +348,16 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   const int ax = iniX & ~3, ox = iniX - ax;           // ox: offset of the cell's first column inside the tile
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
   if (aligned) {
-    // Index arithmetic in 24-bit multiplies (full rate; 32-bit integer multiplies issue at a quarter of it): idx / ndw as
-    // (idx * M) >> 20 with M = 2^20 / ndw + 1, exact for idx < 4096 and ndw < 256; row offsets fit 32 bits (planes <= 4096^2).
-    const int ndw = (ox + tw + 3) >> 2;               // dwords per tile row (<= 18)
-    const uint32_t magic = (1u << 20) / (uint32_t)ndw + 1u;
+    // LDS-DMA: one global_load_lds_dwordx4 per lane moves 16 bytes straight into the tile (no register, no ds_write); the
+    // tile is lane-linear, chunk idx = 5 * row + chunk-in-row.  Chunks past the cell's columns read the bytes that follow
+    // in the plane (a cell window ends >= 13 rows above the plane's last row, so they exist) and are never looked at.
+    // Index arithmetic in 24-bit multiplies (full rate): idx / 5 as (idx * 13108) >> 16, exact below 330 = 5 * 66.
+    const int nch = 5 * th;
     const uint8_t *img0 = img + mul24((uint32_t)iniY, (uint32_t)pitch) + ax;
-    for (int idx = tid; idx < ndw * th; idx += FAST_NT) {
-      const uint32_t r = mul24((uint32_t)idx, magic) >> 20, d = (uint32_t)idx - mul24(r, (uint32_t)ndw);
-      // the last dword of a row may reach past the image row; it stays inside the plane's pitch padding / next row
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(img0 + (mul24(r, (uint32_t)pitch) + 4u * d));
-      *reinterpret_cast<uint32_t *>(&sT[r * FAST_TILE_PITCH + 4 * d]) = v;
+    for (int idx = tid; idx < nch; idx += FAST_NT) {
+      const uint32_t r = mul24((uint32_t)idx, 13108u) >> 16, c = (uint32_t)idx - 5u * r;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img0 + (mul24(r, (uint32_t)pitch) + 16u * c)),
+                                       (__attribute__((address_space(3))) void *)&sT[idx * 16], 16, 0, 0);
     }
   } else {
     const uint32_t magic = (1u << 20) / (uint32_t)tw + 1u;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   __syncthreads();
   FSTAMP(3);
   const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
-  uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (4752 B >= 1024 entries): keeps LDS at ~20 KB = 8 workgroups per CU
+  uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (5280 B >= 900 entries): keeps LDS below 20 KB = 8 workgroups per CU
   const int nkept = (int)sNKept;
   for (int e = tid; e < nkept; e += FAST_NT) {
     const uint32_t v = sKept[e];

@@ -350,7 +350,7 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         const int maxX = std::min(iniX + G.wCell + 6, G.maxBorderX), maxY = std::min(iniY + G.hCell + 6, G.maxBorderY);
         const int tw = maxX - iniX, th = maxY - iniY;
         const bool valid = !(iniX >= G.maxBorderX - 6 || iniY >= G.maxBorderY - 3 || tw - 6 <= 0 || th - 6 <= 0);
-        if (valid && (tw > FAST_TILE_PITCH - 7 || th > FAST_TILE_ROWS)) { h->err = "FAST cell larger than the LDS tile"; return ORBX_E_ARG; }
+        if (valid && (tw > FAST_TILE_COLS || th > FAST_TILE_ROWS)) { h->err = "FAST cell larger than the LDS tile"; return ORBX_E_ARG; }
         R[0] = (uint32_t)iniX | ((uint32_t)iniY << 16);
         R[1] = valid ? ((uint32_t)tw | ((uint32_t)th << 8) | ((uint32_t)l << 16) | (1u << 24)) : ((uint32_t)l << 16);
         R[2] = (uint32_t)(cj * G.wCell) | ((uint32_t)(ci * G.hCell) << 16);
