@@ -974,21 +974,20 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   // with the disc gathers, as 37 rows x 10 aligned dwords into this wave's LDS slice: the BRIEF gathers then never leave
   // the CU and the wave pays one global round trip less.  Keypoints are >= 19 px inside the level, so rows Y-18..Y+18 and
   // columns X-18..X+18 exist; the up to 3 extra bytes of the aligned dwords stay inside the plane's pitch padding / next row.
-  __shared__ uint32_t sPatch[4][37 * 10];
-  uint32_t *myPatch = sPatch[threadIdx.x >> 6];
+  __shared__ __align__(16) uint8_t sPatch[4][37 * 48];
+  uint8_t *myPatch = sPatch[threadIdx.x >> 6];
   const int px0 = (X - 18) & ~3, pox = (X - 18) - px0;
   {
+    // LDS-DMA, 16 bytes per lane straight into the patch (no register, no ds_write): 37 rows x 3 chunks, lane-linear;
+    // idx / 3 as (idx * 21846) >> 16, exact below 111.  The 48-byte rows reach at most 11 bytes past column X+18+3: inside
+    // the plane (the row below exists: keypoints stay 19 px away from the border).
     const uint8_t *brow = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)(Y - 18) * G.bpitch + px0;
-    uint32_t pv[6];
 #pragma unroll
-    for (int t = 0; t < 6; t++) {
-      const int idx = lane + 64 * t, r = idx / 10, d = idx - r * 10;
-      pv[t] = idx < 370 ? *reinterpret_cast<const uint32_t *>(brow + (size_t)r * G.bpitch + 4 * d) : 0u;
-    }
-#pragma unroll
-    for (int t = 0; t < 6; t++) {
-      const int idx = lane + 64 * t;
-      if (idx < 370) myPatch[idx] = pv[t];
+    for (int t = 0; t < 2; t++) {
+      const uint32_t idx = (uint32_t)(lane + 64 * t), r = (idx * 21846u) >> 16, c = idx - 3u * r;
+      if (idx < 111u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(brow + (mul24(r, (uint32_t)G.bpitch) + 16u * c)),
+                                         (__attribute__((address_space(3))) void *)&myPatch[idx * 16], 16, 0, 0);
     }
   }
   int m10 = 0, m01 = 0;
@@ -1013,8 +1012,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   const float arad = angle * factorPI;
   const float a = orbsc::ref_cosf(arad), b = orbsc::ref_sinf(arad);
-  const uint8_t *bc = reinterpret_cast<const uint8_t *>(myPatch) + 18 * 40 + pox + 18;   // patch centre; row pitch 40 B
-  constexpr int bp = 40;
+  const uint8_t *bc = myPatch + 18 * 48 + pox + 18;   // patch centre; row pitch 48 B
+  constexpr int bp = 48;
   unsigned long long bits[4];
   int o0[4], o1[4];
 #pragma unroll
@@ -1024,6 +1023,8 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
     o0[r] = __float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b);
     o1[r] = __float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b);
   }
+  // the patch was written by this wavefront's own LDS-DMA loads (VM counter): long retired by now, but say so
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int v0[4], v1[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) { v0[r] = bc[o0[r]]; v1[r] = bc[o1[r]]; }
