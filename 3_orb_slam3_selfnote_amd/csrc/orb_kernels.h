@@ -778,9 +778,10 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
 // ------------------------------------------------------------------------------------------------------------
 #define BLUR_TX 128
 #define BLUR_TY 32
+#define BLUR_IN_PITCH 36   // dwords per input tile row
 __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   // input tile: rows y0-3 .. y0+34 (38), columns x0-4 .. x0+131 (136 B = 34 dwords); row sums: 38 x 128 u16
-  __shared__ uint32_t sIn[38 * 34];
+  __shared__ __align__(16) uint32_t sIn[38 * BLUR_IN_PITCH];   // 144-byte rows = nine 16-byte LDS-DMA chunks (136 bytes are used)
   __shared__ __align__(16) uint32_t sRow[19 * 128];  // vertical pairs of row sums: [row pair][column]
   const int tid = threadIdx.x;
   int tile, frame;
@@ -797,12 +798,15 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   else { pitch = (int)(t0.w & 0xffffu); img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)t1.y << 32) | t1.x); }
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
   // interior tiles (the majority): no reflection anywhere, plain coalesced dword rows.  Decided once per workgroup.
-  const bool interior = aligned && x0 >= 4 && x0 + BLUR_TX + 4 <= G.w && y0 >= 3 && y0 + BLUR_TY + 3 <= G.h;
+  const bool interior = aligned && x0 >= 4 && x0 + BLUR_TX + 12 <= G.w && y0 >= 3 && y0 + BLUR_TY + 3 <= G.h;   // + 12: the 144-byte rows
   if (interior) {
+    // LDS-DMA: 38 rows x 9 chunks of 16 bytes, lane-linear, straight into the tile (idx / 9 as (idx * 7282) >> 16, exact
+    // below 342).  The ninth chunk reaches 8 bytes past column x0 + 131: still inside the row (see `interior`).
     const uint8_t *base = img + (size_t)(y0 - 3) * pitch + (x0 - 4);
-    for (int idx = tid; idx < 38 * 34; idx += 256) {
-      const uint32_t r = mul24((uint32_t)idx, 1928u) >> 16, c = (uint32_t)idx - r * 34u;   // idx / 34, exact below 1292
-      sIn[idx] = *reinterpret_cast<const uint32_t *>(base + (mul24(r, (uint32_t)pitch) + 4u * c));
+    for (int idx = tid; idx < 38 * 9; idx += 256) {
+      const uint32_t r = mul24((uint32_t)idx, 7282u) >> 16, c = (uint32_t)idx - 9u * r;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (mul24(r, (uint32_t)pitch) + 16u * c)),
+                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<uint8_t *>(sIn) + idx * 16), 16, 0, 0);
     }
   } else {
     // border tiles: one reflection step is enough whenever the level is larger than the halo (always, except degenerate
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
           v |= (uint32_t)row[xx] << (8 * k);
         }
       }
-      sIn[idx] = v;
+      sIn[r * BLUR_IN_PITCH + c] = v;
     }
   }
   __syncthreads();
@@ -851,8 +855,8 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   for (int idx = tid; idx < 19 * 32; idx += 256) {
     const int rp = idx >> 5, q = idx & 31;
     uint32_t sa[4], sb[4];
-    hsum4(&sIn[(2 * rp) * 34 + q], sa);
-    hsum4(&sIn[(2 * rp + 1) * 34 + q], sb);
+    hsum4(&sIn[(2 * rp) * BLUR_IN_PITCH + q], sa);
+    hsum4(&sIn[(2 * rp + 1) * BLUR_IN_PITCH + q], sb);
     *reinterpret_cast<uint4 *>(&sRow[rp * 128 + 4 * q]) = make_uint4(sa[0] | (sb[0] << 16), sa[1] | (sb[1] << 16), sa[2] | (sb[2] << 16), sa[3] | (sb[3] << 16));
   }
   __syncthreads();
