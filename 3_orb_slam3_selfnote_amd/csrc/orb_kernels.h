@@ -810,30 +810,44 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
     }
   } else {
     // border tiles: one reflection step is enough whenever the level is larger than the halo (always, except degenerate
-    // configurations, which take the general loop); columns far beyond the right edge only feed outputs nobody stores
+    // configurations, which take the general loop); columns far beyond the right edge only feed outputs nobody stores.
+    // Two loops: the dwords that lie inside the image row are plain aligned loads from the (row-reflected) source row;
+    // the few dword columns that touch the left or right image edge - cE of the 34, typically 1 or 5 - are visited by a
+    // second, short loop.  In one loop every wavefront would pay for the byte-wise reflection (each holds an edge dword).
     const bool small = G.w < 16 || G.h < 16;
-    for (int idx = tid; idx < 38 * 34; idx += 256) {
-      const int r = idx / 34, c = idx - r * 34;
+    auto srcRow = [&](int r) {
       int yy = y0 + r - 3;
       if (small) yy = reflect101(yy, G.h);
       else { yy = yy < 0 ? -yy : yy; yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy; yy = max(yy, 0); }
+      return img + mul24((uint32_t)yy, (uint32_t)pitch);
+    };
+    // plain columns: xb = x0 - 4 + 4c with 0 <= xb and xb + 3 < w  <=>  cL <= c < cR
+    const int cL = aligned ? (x0 >= 4 ? 0 : 1) : 34;
+    const int cR = aligned ? min(34, max(cL, (G.w - x0 + 4) >> 2)) : 34;   // first c with xb + 3 >= w
+    const int cE = cL + (34 - cR);
+    for (int idx = tid; idx < 38 * 34; idx += 256) {
+      const uint32_t r = mul24((uint32_t)idx, 1928u) >> 16, c = (uint32_t)idx - r * 34u;
+      if ((int)c >= cL && (int)c < cR) sIn[r * BLUR_IN_PITCH + c] = *reinterpret_cast<const uint32_t *>(srcRow((int)r) + (x0 - 4 + 4 * (int)c));
+    }
+    const float inv_cE = 1.0f / (float)max(cE, 1);
+    for (int j = tid; j < 38 * cE; j += 256) {
+      const int r = (int)(((float)j + 0.5f) * inv_cE), k = j - r * cE;   // exact: j < 1292, see k_resize
+      const int c = k < cL ? k : cR + (k - cL);
       const int xb = x0 - 4 + 4 * c;
-      const uint8_t *row = img + (size_t)yy * pitch;
+      const uint8_t *row = srcRow(r);
       uint32_t v;
-      if (aligned && xb >= 0 && xb + 3 < G.w) {
-        v = *reinterpret_cast<const uint32_t *>(row + xb);
-      } else if (small) {
+      if (small) {
         v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
             ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
       } else {
         v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          int xx = xb + k;
+        for (int kk = 0; kk < 4; kk++) {
+          int xx = xb + kk;
           xx = xx < 0 ? -xx : xx;
           xx = xx >= G.w ? 2 * (G.w - 1) - xx : xx;
           xx = max(xx, 0);                      // only for columns >= w + w - 1: never part of a stored output
-          v |= (uint32_t)row[xx] << (8 * k);
+          v |= (uint32_t)row[xx] << (8 * kk);
         }
       }
       sIn[r * BLUR_IN_PITCH + c] = v;
