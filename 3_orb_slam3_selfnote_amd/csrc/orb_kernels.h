@@ -180,11 +180,22 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   if (nsrc <= RESIZE_MAXSRC) {
     const uint8_t *src0 = src + (size_t)syFirst * spitch;
     if (aligned) {
-      const int ndw = (Gs.w + 3) >> 2;  // the last dword may read up to 3 bytes of row padding / next row: inside the plane
+      // Full 16-byte chunks of every source row by LDS-DMA (global_load_lds_dwordx4: no register, no ds_write).  The LDS rows
+      // are smemRowBytes = 16 * cpr long; the loop runs over all cpr chunk positions so that the LDS image stays lane-linear
+      // (destination = wave base + lane * 16), the positions past the last full chunk simply stay inactive.
+      const int cpr = smemRowBytes >> 4, nfull = Gs.w >> 4;
+      const float inv_cpr = 1.0f / (float)cpr;
+      for (int idx = tid; idx < cpr * nsrc; idx += 256) {
+        const int r = (int)(((float)idx + 0.5f) * inv_cpr), c = idx - (int)mul24((uint32_t)r, (uint32_t)cpr);
+        if (c < nfull)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + (mul24((uint32_t)r, (uint32_t)spitch) + 16u * (uint32_t)c)),
+                                           (__attribute__((address_space(3))) void *)(sRows + (size_t)(idx - (tid & 63)) * 16), 16, 0, 0);
+      }
+      // the tail of every row (< 16 bytes, up to 4 dwords) through registers
+      const int ndw = (Gs.w + 3) >> 2, d0 = 4 * nfull, ntail = ndw - d0;   // the last dword may read up to 3 bytes of row padding / next row: inside the plane
       const bool lastRowPartial = (Gs.w & 3) != 0;
-      const float inv_ndw = 1.0f / (float)ndw;
-      for (int idx = tid; idx < ndw * nsrc; idx += 256) {
-        const int r = (int)(((float)idx + 0.5f) * inv_ndw), d = idx - (int)mul24((uint32_t)r, (uint32_t)ndw);
+      for (int idx = tid; idx < ntail * nsrc; idx += 256) {
+        const int r = idx / ntail, d = d0 + (idx - r * ntail);
         const uint8_t *rowp = src0 + mul24((uint32_t)r, (uint32_t)spitch);
         uint32_t v;
         if (lastRowPartial && d == ndw - 1 && syFirst + r == Gs.h - 1 && spitch < 4 * ndw) {
