@@ -1029,8 +1029,28 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
       dv[t] = (int)(int8_t)(vw[t >> 2] >> (8 * (t & 3)));
     }
   }
+  // The disc pixels: when the level plane is dword-aligned, its 31 rows x 48 bytes around the keypoint come in by LDS-DMA
+  // as well (two 16-byte chunks per lane instead of twelve scattered byte gathers) and the disc is read from LDS.
+  __shared__ __align__(16) uint8_t sDisc[4][31 * 48];
+  uint8_t *myDisc = sDisc[threadIdx.x >> 6];
+  if (((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0) {
+    const int qx0 = (X - 15) & ~3, qox = (X - 15) - qx0;
+    const uint8_t *irow = img + (size_t)(Y - 15) * pitch + qx0;
 #pragma unroll
-  for (int t = 0; t < 12; t++) dval[t] = centre[dv[t] * pitch + du[t]];
+    for (int t = 0; t < 2; t++) {
+      const uint32_t idx = (uint32_t)(lane + 64 * t), r = (idx * 21846u) >> 16, c = idx - 3u * r;
+      if (idx < 93u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(irow + (mul24(r, (uint32_t)pitch) + 16u * c)),
+                                         (__attribute__((address_space(3))) void *)&myDisc[idx * 16], 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both patches have landed
+    const uint8_t *dc = myDisc + 15 * 48 + qox + 15;
+#pragma unroll
+    for (int t = 0; t < 12; t++) dval[t] = dc[dv[t] * 48 + du[t]];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 12; t++) dval[t] = centre[dv[t] * pitch + du[t]];
+  }
 #pragma unroll
   for (int t = 0; t < 12; t++) { m10 += du[t] * dval[t]; m01 += dv[t] * dval[t]; }
   m10 = wave_sum_i32(m10);
