@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   __shared__ int sCol[66 + 66];  // column starts (65 bins + end), then the scatter cursors
   __shared__ int sCmd;           // number of refresh requests posted, -1 = exit
   __shared__ uint32_t sReq[RESOLVE_NW][REQ_WORDS];
+  __shared__ K sPart[RESOLVE_NW][RESOLVE_NW][REFRESH_K];   // [request][share]: each serving wavefront's REFRESH_K best keys
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -427,7 +428,11 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   };
   // One wavefront serves refresh request `rq`: the REFRESH_K smallest keys of the query's window among the keypoints
   // no committed claim holds -> column `target lane` of sTk.
-  auto serve = [&](int rq) {
+  // A pass serves m <= RESOLVE_NW requests with all RESOLVE_NW wavefronts: mp = m rounded up to a power of two, every request
+  // gets RESOLVE_NW / mp wavefronts, each scanning an interleaved share of the window's keypoints; the requesting lane merges
+  // the shares' sorted lists.  Most passes carry one or two requests, which then finish 8 or 4 times sooner.
+  auto shares_of = [](int m) { return m <= 1 ? RESOLVE_NW : m <= 2 ? RESOLVE_NW / 2 : m <= 4 ? RESOLVE_NW / 4 : 1; };
+  auto serve = [&](int rq, int part, int nparts) {
     const uint32_t *R = sReq[rq];
     const int target = (int)R[0];
     QueryWin w;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       }
     };
     const int end = w.live ? sCol[w.cx1 + 1] : 0;
-    for (int pos = (w.live ? sCol[w.cx0] : 0) + lane; pos < end; pos += 128) {  // two keypoints in flight per lane
+    for (int pos = (w.live ? sCol[w.cx0] : 0) + lane + 128 * part; pos < end; pos += 128 * nparts) {  // two keypoints in flight per lane
       const Cand k0 = fetch(pos, true);
       const Cand k1 = fetch(pos + 64, pos + 64 < end);
       consider(k0);
@@ -515,8 +520,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     }
     if (lane == 0) {
 #pragma unroll
-      for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + target] = j < REFRESH_K ? out[j] : KT::NONE;
+      for (int j = 0; j < REFRESH_K; j++) sPart[rq][part][j] = out[j];
     }
+    (void)target;
   };
 #ifdef RESOLVE_STAMPS
   long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0;
@@ -528,8 +534,11 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       __syncthreads();                 // (A) requests posted
       const int m = sCmd;
       if (m < 0) break;
-      if (wid < m) serve(wid);
-      __syncthreads();                 // (B) lists written
+      {
+        const int np = shares_of(m), mp = RESOLVE_NW / np, rq = wid & (mp - 1);
+        if (rq < m) serve(rq, wid / mp, np);
+      }
+      __syncthreads();                 // (B) shares written
     }
   } else {
     int nmatches = 0;
@@ -601,8 +610,29 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           const int m = min(RESOLVE_NW, (int)__popcll(todo));
           if (lane == 0) sCmd = m;
           __syncthreads();             // (A)
-          serve(0);
+          const int np = shares_of(m);
+          serve(0, 0, np);
           __syncthreads();             // (B)
+          if (take) {
+            // merge the np sorted shares of my request: min(A[i], B[K-1-i]) are the K smallest of a pair's union (a bitonic
+            // sequence), two compare-exchange stages sort them; the rest of my column is empty
+            static_assert(REFRESH_K == 4, "the merge network below is written for 4 keys");
+            auto cx = [](K &lo, K &hi) { const K l = lo < hi ? lo : hi, h = lo < hi ? hi : lo; lo = l; hi = h; };
+            K a[REFRESH_K];
+#pragma unroll
+            for (int j = 0; j < REFRESH_K; j++) a[j] = sPart[rank][0][j];
+            for (int sh = 1; sh < np; sh++) {
+#pragma unroll
+              for (int j = 0; j < REFRESH_K; j++) {
+                const K y = sPart[rank][sh][REFRESH_K - 1 - j];
+                a[j] = a[j] < y ? a[j] : y;
+              }
+              cx(a[0], a[2]); cx(a[1], a[3]);
+              cx(a[0], a[1]); cx(a[2], a[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + lane] = j < REFRESH_K ? a[j] : KT::NONE;
+          }
           todo &= ~__ballot(take);
 #ifdef RESOLVE_STAMPS
           n_batch++;
