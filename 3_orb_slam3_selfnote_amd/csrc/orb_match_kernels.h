@@ -455,9 +455,12 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     for (int j = 0; j < REFRESH_K; j++) l[j] = KT::NONE;
     // level filter as a closed interval (open ends when disabled), window test in sign-bit arithmetic as in k_match_scan
     const int minlE = w.checkLevels ? w.minl : -1000, maxlE = w.checkLevels && w.maxl >= 0 ? w.maxl : 1000;
-    struct Cand { float x, y, ur; uint32_t bits, d[8]; int c; };
-    auto fetch = [&](int pos, bool valid) {
-      Cand k;
+    // Two steps per keypoint: its 16-byte record (position, cell, octave, usable bit) and owner word decide whether it is a
+    // candidate at all; only then are the 32 descriptor bytes read.  Late in a frame most keypoints are claimed, and the scan
+    // is bound by LDS throughput (random 16-byte reads), so not touching their descriptors is most of the saving.
+    struct Probe { float x, y, ur; uint32_t bits; int c; };
+    auto probe = [&](int pos, bool valid) {
+      Probe k;
       k.c = valid ? (int)sPerm[pos] : -1;
       const int c = valid ? k.c : 0;
       const bool cl = sOwner[valid ? c : n] == 0u;
@@ -465,18 +468,14 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         const CandMeta cmeta = sMeta[c];
         k.x = cmeta.x; k.y = cmeta.y; k.ur = cmeta.ur;
         k.bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
-        const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-        k.d[0] = a.x; k.d[1] = a.y; k.d[2] = a.z; k.d[3] = a.w; k.d[4] = b.x; k.d[5] = b.y; k.d[6] = b.z; k.d[7] = b.w;
       } else {
         k.x = kp[(size_t)c * 7]; k.y = kp[(size_t)c * 7 + 1];
         k.bits = cand_bits(k.x, k.y, __float_as_int(kp[(size_t)c * 7 + 5]), cl, M);
         k.ur = M.u_right ? M.u_right[fo + c] : -1.f;
-#pragma unroll
-        for (int t = 0; t < 8; t++) k.d[t] = desc[(size_t)c * 8 + t];
       }
       return k;
     };
-    auto consider = [&](const Cand &k) {
+    auto passes = [&](const Probe &k) {
       const int gx = (k.bits >> 8) & 0xff, gy = (k.bits >> 16) & 0xff, oct = k.bits & 0xff;
       int viol = (gx - w.cx0) | (w.cx1 - gx) | (gy - w.cy0) | (w.cy1 - gy) | (oct - minlE) | (maxlE - oct) | k.c;
       viol |= ((k.c >= nleft) == sideR) ? 0 : -1;
@@ -484,28 +483,38 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       const int fpass = __float_as_int(fabsf(k.x - w.u) - w.r) & __float_as_int(fabsf(k.y - w.v) - w.r);
       bool ok = (fpass & ~viol) < 0;
       if (w.stereo) ok = ok && !(k.ur > 0.f && fabsf(w.ur - k.ur) > w.r);   // ORBmatcher.cc:93-98, :2139-2146
-      if (ok) {
-        int dist = 0;
+      return ok;
+    };
+    auto score = [&](const Probe &k) {
+      uint32_t d[8];
+      if (LDSCAND) {
+        const uint4 a = sDesc[2 * k.c], b = sDesc[2 * k.c + 1];
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+      } else {
 #pragma unroll
-        for (int t = 0; t < 8; t++) dist += __popc(k.d[t] ^ q8[t]);
-        K t = KT::make(dist, cell_of(k.bits), k.c);
-        if (t < l[REFRESH_K - 1]) {
+        for (int t = 0; t < 8; t++) d[t] = desc[(size_t)k.c * 8 + t];
+      }
+      int dist = 0;
 #pragma unroll
-          for (int j = 0; j < REFRESH_K; j++) {
-            const K lo = t < l[j] ? t : l[j];
-            const K hi = t < l[j] ? l[j] : t;
-            l[j] = lo;
-            t = hi;
-          }
+      for (int t = 0; t < 8; t++) dist += __popc(d[t] ^ q8[t]);
+      K t = KT::make(dist, cell_of(k.bits), k.c);
+      if (t < l[REFRESH_K - 1]) {
+#pragma unroll
+        for (int j = 0; j < REFRESH_K; j++) {
+          const K lo = t < l[j] ? t : l[j];
+          const K hi = t < l[j] ? l[j] : t;
+          l[j] = lo;
+          t = hi;
         }
       }
     };
     const int end = w.live ? sCol[w.cx1 + 1] : 0;
     for (int pos = (w.live ? sCol[w.cx0] : 0) + lane + 128 * part; pos < end; pos += 128 * nparts) {  // two keypoints in flight per lane
-      const Cand k0 = fetch(pos, true);
-      const Cand k1 = fetch(pos + 64, pos + 64 < end);
-      consider(k0);
-      consider(k1);
+      const Probe k0 = probe(pos, true);
+      const Probe k1 = probe(pos + 64, pos + 64 < end);
+      const bool ok0 = passes(k0), ok1 = passes(k1);
+      if (ok0) score(k0);
+      if (ok1) score(k1);
     }
     // REFRESH_K extractions of the wave minimum; keys are unique, so exactly one lane pops per extraction
     K out[REFRESH_K];
