@@ -377,13 +377,15 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
   int32_t *slot = M.slot + fo;
   uint8_t *slot_obs = M.slot_obs + fo;
-  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only) [owner maxn+1][slot maxn][perm: maxn u16]
+  // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only, both in sPerm order: the refresh scan then reads them
+  // sequentially, conflict-free, instead of at random) [owner maxn+1][slot maxn][perm: maxn u16][partner][octave: maxn u8]
   uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
   CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
   uint32_t *sOwner = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
   int32_t *sSlot = reinterpret_cast<int32_t *>(sOwner + maxn + 1);
   uint16_t *sPerm = reinterpret_cast<uint16_t *>(sSlot + maxn);
   uint16_t *sPartner = sPerm + ((maxn + 1) & ~1);   // stereo partner of each keypoint, 0xffff = none (only if M.partner)
+  uint8_t *sOct = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(sPartner) + (M.partner ? (maxn + 1) / 2 + 1 : 0));
   int *sFill = sCol + 66;
   for (int i = tid; i < 132; i += 64 * RESOLVE_NW) sCol[i] = 0;
   __syncthreads();
@@ -392,21 +394,12 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     sSlot[i] = -1;
     const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
     const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
-    if (LDSCAND) {
-      CandMeta c;
-      c.x = x; c.y = y; c.bits = bits;
-      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
-      sMeta[i] = c;
-    }
+    sOct[i] = (uint8_t)(bits & 0xffu);
     atomicAdd(&sCol[((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) + 1 : 65], 1);  // histogram shifted by one
   }
   if (tid == 0) sOwner[n] = RESOLVE_FREE;
   if (M.partner)
     for (int i = tid; i < n; i += 64 * RESOLVE_NW) { const int32_t pr = M.partner[fo + i]; sPartner[i] = (uint16_t)(pr >= 0 && pr < n ? pr : 0xffff); }
-  if (LDSCAND) {
-    const uint4 *gd = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
-    for (int i = tid; i < 2 * n; i += 64 * RESOLVE_NW) sDesc[i] = gd[i];
-  }
   __syncthreads();
   if (tid == 0) {  // exclusive prefix: sCol[c] = first position of column c, sCol[64] = end of the in-grid keypoints
     int acc = 0;
@@ -414,18 +407,23 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   }
   __syncthreads();
   for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
-    uint32_t bits;
-    if (LDSCAND) bits = sMeta[i].bits;
-    else bits = cand_bits(kp[(size_t)i * 7], kp[(size_t)i * 7 + 1], __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
+    const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
+    const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
     const int col = ((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) : 64;
     const int pos = sCol[col] + atomicAdd(&sFill[col], 1);
     sPerm[pos] = (uint16_t)i;
+    if (LDSCAND) {   // record and descriptor of keypoint i live at its sorted position
+      CandMeta c;
+      c.x = x; c.y = y; c.bits = bits;
+      c.ur = M.u_right ? M.u_right[fo + i] : -1.f;
+      sMeta[pos] = c;
+      const uint4 *gd = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
+      sDesc[2 * pos] = gd[2 * i];
+      sDesc[2 * pos + 1] = gd[2 * i + 1];
+    }
   }
   __syncthreads();
-  auto octave_of = [&](int idx) -> int {
-    if (LDSCAND) return (int)(sMeta[idx].bits & 0xff);
-    return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
-  };
+  auto octave_of = [&](int idx) -> int { return (int)sOct[idx]; };
   // One wavefront serves refresh request `rq`: the REFRESH_K smallest keys of the query's window among the keypoints
   // no committed claim holds -> column `target lane` of sTk.
   // A pass serves m <= RESOLVE_NW requests with all RESOLVE_NW wavefronts: mp = m rounded up to a power of two, every request
@@ -458,14 +456,15 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     // Two steps per keypoint: its 16-byte record (position, cell, octave, usable bit) and owner word decide whether it is a
     // candidate at all; only then are the 32 descriptor bytes read.  Late in a frame most keypoints are claimed, and the scan
     // is bound by LDS throughput (random 16-byte reads), so not touching their descriptors is most of the saving.
-    struct Probe { float x, y, ur; uint32_t bits; int c; };
+    struct Probe { float x, y, ur; uint32_t bits; int c, pos; };
     auto probe = [&](int pos, bool valid) {
       Probe k;
       k.c = valid ? (int)sPerm[pos] : -1;
+      k.pos = valid ? pos : 0;
       const int c = valid ? k.c : 0;
       const bool cl = sOwner[valid ? c : n] == 0u;
       if (LDSCAND) {
-        const CandMeta cmeta = sMeta[c];
+        const CandMeta cmeta = sMeta[k.pos];
         k.x = cmeta.x; k.y = cmeta.y; k.ur = cmeta.ur;
         k.bits = cl ? (cmeta.bits & ~(1u << 24)) : cmeta.bits;
       } else {
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     auto score = [&](const Probe &k) {
       uint32_t d[8];
       if (LDSCAND) {
-        const uint4 a = sDesc[2 * k.c], b = sDesc[2 * k.c + 1];
+        const uint4 a = sDesc[2 * k.pos], b = sDesc[2 * k.pos + 1];
         d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
       } else {
 #pragma unroll

@@ -1053,8 +1053,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
   if (prof) MCHECK(m, hipEventRecord(pev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
-  // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16); see k_match_resolve
-  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
+  // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16), partner list, octave bytes; see k_match_resolve
+  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + (maxn + 3) / 4 + 2);
   const size_t big = small + 48 * (size_t)maxn;
   const bool ldscand = big <= 150 * 1024;
   const size_t lds = ldscand ? big : small;
