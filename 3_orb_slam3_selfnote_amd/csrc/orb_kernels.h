@@ -167,9 +167,11 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const int syLast = min(max(P.ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), Gs.h - 1);
   const int nsrc = syLast - syFirst + 1;
   int2 *sX = reinterpret_cast<int2 *>(smem_rs);                       // [G.w]
-  const size_t sRowsOff = ((size_t)G.w * 8 + 15) & ~(size_t)15;
+  // the x table is padded to whole output quads with copies of its last entry: the row loop then needs no column clamp
+  const int wq = (G.w + 3) & ~3;
+  const size_t sRowsOff = ((size_t)wq * 8 + 15) & ~(size_t)15;
   uint8_t *sRows = smem_rs + sRowsOff;   // [nsrc][smemRowBytes]
-  for (int i = tid; i < G.w; i += 256) sX[i] = P.xtab[G.xtabBase + i];
+  for (int i = tid; i < wq; i += 256) sX[i] = P.xtab[G.xtabBase + min(i, G.w - 1)];
   // the tile's y-coefficients go through LDS as well: the row loop below then has no global load in front of its gathers
   __shared__ int2 sY[RESIZE_ROWS];
   if (tid < nrows) sY[tid] = P.ytab[G.ytabBase + dy0 + tid];
@@ -232,8 +234,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
       uint32_t packed = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int dx = min(dx0 + j, G.w - 1);   // columns past the row end recompute the last one; only [0, w) is stored
-        const int2 xt = sX[dx];
+        const int2 xt = sX[dx0 + j];            // columns past the row end repeat the last one (padded table); only [0, w) is stored
         const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
         const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
         const int r0 = S0[sx] * a0 + S0[sx1] * a1;

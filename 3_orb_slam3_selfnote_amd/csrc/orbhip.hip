@@ -513,7 +513,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   for (int l = 1; l < h->nlevels; l++) {
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
-    const size_t lds = align_up((size_t)G.w * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;
+    const size_t lds = align_up((size_t)((G.w + 3) & ~3) * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;   // x table padded to whole quads
     if (lds > 48 * 1024) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
   }
