@@ -76,8 +76,8 @@ def cpu_baseline(frames, offs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=80)   # 80 x 256 frames: the drain of the 4-deep pipeline at the end is ~3 % of the region
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (steps alternate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
