@@ -167,6 +167,10 @@ def main():
     pipes = [Pipe() for _ in range(max(1, args.streams))]
     cap = pipes[0].cap
     level_shapes = [pipes[0].ex.level_shape(l) for l in range(CFG["nlevels"])]
+    # set-up: every pipeline runs once so that its lazily sized device buffers and kernel attributes exist before any step is
+    # counted, whatever --warmup is (the W warm-up steps below alternate between the pipelines like the timed ones)
+    for pp in pipes:
+        pp.step()
     torch.cuda.synchronize()
     counter = [0]
 
