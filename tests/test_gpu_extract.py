@@ -208,6 +208,8 @@ def test_full_size_properties(pkg, frame):
     dict(H=256, W=300, nfeatures=64, scaleFactor=2.0, nlevels=3, iniThFAST=30, minThFAST=30),      # octave pyramid, ini == min threshold
     dict(H=200, W=260, nfeatures=20, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),       # tiny quotas (some levels get 1-2 features)
     dict(H=130, W=150, nfeatures=500, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),      # upper levels smaller than one cell
+    dict(H=1080, W=1920, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),   # full HD: long rows in every staging loop
+    dict(H=613, W=1021, nfeatures=1200, scaleFactor=1.3, nlevels=6, iniThFAST=15, minThFAST=5),    # odd sizes: unaligned level-0 rows, ragged row tails
 ])
 def test_extract_parity_config_matrix(pkg, oracle, synth, cfg):
     """Geometry / parameter sweep: other datasets' image sizes, scale factors, level counts, thresholds, quotas."""
