@@ -301,3 +301,23 @@ def test_blur_saturation_and_borders(ex, oex, oracle):
         ref = oracle.gaussian_blur7(pyr[l])
         assert np.array_equal(ex.blurred_level(l), ref), "blur level %d" % l
     assert (oracle.gaussian_blur7(pyr[0]) == 255).any()
+
+
+def test_maximum_image_size(pkg, oracle, synth):
+    """The largest supported image (4096 x 4096, 12-bit packed coordinates) extracts bit-exactly; one pixel more is refused."""
+    rng = np.random.default_rng(4096)
+    small = synth.make_frame(4096, 512, 512)
+    img = np.kron(small, np.ones((8, 8), np.uint8))
+    img = (img.astype(np.int32) + rng.integers(-12, 13, img.shape)).clip(0, 255).astype(np.uint8)
+    e = pkg.ORBextractor(2000, 1.2, 8, 20, 7)
+    o = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    try:
+        mono, kps, desc = e(img, None, (0, 0))
+        mono_r, kps_r, desc_r = o.extract(img, (0, 0))
+        assert mono == mono_r and len(kps) > 1500
+        assert_kps_equal(kps, kps_r)
+        assert np.array_equal(desc, desc_r)
+        with pytest.raises((pkg.OrbError, ValueError)):
+            e(np.zeros((4097, 64), np.uint8), None, (0, 0))
+    finally:
+        e.close()
