@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   int32_t *slot = M.slot + fo;
   uint8_t *slot_obs = M.slot_obs + fo;
   // carve: [desc 8*maxn words][meta 4*maxn words] (LDSCAND only, both in sPerm order: the refresh scan then reads them
-  // sequentially, conflict-free, instead of at random) [owner maxn+1][slot maxn][perm: maxn u16][partner][octave: maxn u8]
+  // sequentially, conflict-free, instead of at random) [owner maxn+1][slot maxn][perm: maxn u16][partner][octave: maxn u8 (LDSCAND only)]
   uint4 *sDesc = reinterpret_cast<uint4 *>(smem_resolve);
   CandMeta *sMeta = reinterpret_cast<CandMeta *>(smem_resolve + (LDSCAND ? 8 * (size_t)maxn : 0));
   uint32_t *sOwner = smem_resolve + (LDSCAND ? 12 * (size_t)maxn : 0);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     sSlot[i] = -1;
     const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
     const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
-    sOct[i] = (uint8_t)(bits & 0xffu);
+    if (LDSCAND) sOct[i] = (uint8_t)(bits & 0xffu);
     atomicAdd(&sCol[((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) + 1 : 65], 1);  // histogram shifted by one
   }
   if (tid == 0) sOwner[n] = RESOLVE_FREE;
@@ -423,7 +423,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     }
   }
   __syncthreads();
-  auto octave_of = [&](int idx) -> int { return (int)sOct[idx]; };
+  auto octave_of = [&](int idx) -> int {
+    if (LDSCAND) return (int)sOct[idx];
+    return __float_as_int(kp[(size_t)idx * 7 + 5]) & 0xff;
+  };
   // One wavefront serves refresh request `rq`: the REFRESH_K smallest keys of the query's window among the keypoints
   // no committed claim holds -> column `target lane` of sTk.
   // A pass serves m <= RESOLVE_NW requests with all RESOLVE_NW wavefronts: mp = m rounded up to a power of two, every request

@@ -1054,10 +1054,11 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (prof) MCHECK(m, hipEventRecord(pev[0], s));
   const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16), partner list, octave bytes; see k_match_resolve
-  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + (maxn + 3) / 4 + 2);
-  const size_t big = small + 48 * (size_t)maxn;
+  const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
+  const size_t big = small + sizeof(uint32_t) * (size_t)((maxn + 3) / 4) + 48 * (size_t)maxn;   // + octave bytes, records, descriptors
   const bool ldscand = big <= 150 * 1024;
   const size_t lds = ldscand ? big : small;
+  if (lds > 160 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
   const dim3 rblock(64 * RESOLVE_NW);
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \

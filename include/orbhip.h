@@ -164,6 +164,8 @@ int orbx_compute_stereo_matches(orbx_t *left, int frame_l, orbx_t *right, int fr
 #define ORBM_GRID_COLS 64 /* Frame.h:38 */
 #define ORBM_GRID_ROWS 48 /* Frame.h:39 */
 #define ORBM_MAX_KEYPOINTS 15360 /* per frame, projection search: its claim state lives in one CU's LDS */
+/* Fisheye-stereo searches (orbm_search_by_projection_fisheye, ..._last_frame_fisheye) keep a partner list in LDS as well and
+ * take up to about 13 000 keypoints (left + right); beyond that they return ORBX_E_ARG. */
 
 typedef struct orbm_handle orbm_t;
 orbm_t *orbm_create(int device);

@@ -78,11 +78,12 @@ def test_search_stress_1000x1000(pkg, oracle, synth, matcher):
     assert np.array_equal(F.slot, OF.slot)
 
 
-@pytest.mark.parametrize("N", [600, 4000])
+@pytest.mark.parametrize("N", [600, 4000, 15360])
 def test_claims_and_ties(pkg, oracle, matcher, N):
     """Collisions: duplicated descriptors (distance ties decided by grid-walk order), duplicated queries (later
     queries lose a claimed keypoint only if the holder has observations), pre-occupied slots.
-    N = 4000 exceeds the LDS-resident candidate copy of the resolve kernel (global-memory rescan path)."""
+    N = 4000 exceeds the LDS-resident candidate copy of the resolve kernel (global-memory rescan path); 15360 is the
+    largest frame the search kernels take (ORBM_MAX_KEYPOINTS), one keypoint more is refused."""
     rng = np.random.default_rng(11)
     kps = np.zeros(N, dtype=pkg.KP_DTYPE)
     kps["x"] = rng.uniform(5, 747, N).astype(np.float32)
@@ -119,6 +120,11 @@ def test_claims_and_ties(pkg, oracle, matcher, N):
         assert np.array_equal(moq_gpu, moq_ref) and np.array_equal(bd_gpu, bd_ref)
         assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
         OF.slot_obs[:] = so0; F.slot_obs[:] = so0
+    if N == 15360:
+        big = np.concatenate([kps, kps[:1]])
+        F2 = pkg.FrameView(big, np.concatenate([desc, desc[:1]]), (0.0, 752.0, 0.0, 480.0))
+        with pytest.raises((pkg.OrbError, ValueError)):
+            matcher.search_window(F2, qdesc, u, v, radius, minl, maxl, flags=flags, nnratio=0.7, th_dist=60, use_second=True)
 
 
 def test_empty_and_ragged(pkg, oracle, matcher):
