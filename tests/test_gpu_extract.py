@@ -97,6 +97,28 @@ def test_ini_extractor_5000(pkg, oracle, frame):
     e.close()
 
 
+def test_ini_extractor_10000(pkg, oracle):
+    """5 * nFeatures for KITTI's 2000 features (Examples/Monocular/KITTI00-02.yaml): 2172 features on level 0, just inside
+    the LDS-resident octree; noise image so that every quota is reached.  12000 is refused loudly."""
+    img = np.random.default_rng(10000).integers(0, 256, (376, 1241), dtype=np.uint8)
+    e = pkg.ORBextractor(10000, 1.2, 8, 20, 7)
+    o = oracle.OracleExtractor(10000, 1.2, 8, 20, 7)
+    try:
+        mono, kps, desc = e(img, None, (0, 0))
+        mono_r, kps_r, desc_r = o.extract(img, (0, 0))
+        assert mono == mono_r and len(kps_r) > 9000
+        assert_kps_equal(kps, kps_r)
+        assert np.array_equal(desc, desc_r)
+    finally:
+        e.close()
+    e2 = pkg.ORBextractor(12000, 1.2, 8, 20, 7)
+    try:
+        with pytest.raises((pkg.OrbError, ValueError)):
+            e2(img, None, (0, 0))
+    finally:
+        e2.close()
+
+
 def test_lapping_partial(ex, oex, frame):
     img = frame(1002)
     for lap in [(300, 500), (0, 375), (376, 2000)]:
