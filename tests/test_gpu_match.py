@@ -381,7 +381,7 @@ def test_search_by_projection_last_frame_m3_fisheye(pkg, oracle, synth, matcher,
     assert total > (100 if cam == 0 else 0)
 
 
-@pytest.mark.parametrize("nfeatures,window", [(1000, 100), (5000, 100), (5000, 30)])
+@pytest.mark.parametrize("nfeatures,window", [(1000, 100), (5000, 100), (5000, 30), (10000, 100)])
 def test_search_for_initialization_n2(pkg, oracle, synth, nfeatures, window):
     """ORBmatcher::SearchForInitialization (ORBmatcher.cc:722-837): level-0 window search with the vMatchedDistance rule,
     match stealing, rotation histogram and the vbPrevMatched update.  5000 features = the initialisation extractor
