@@ -37,7 +37,7 @@ def random_image(rng, H, W, synth):
 def fuzz_extract(pkg, oracle, synth, rng, log, cache):
     H, W = int(rng.integers(96, 640)), int(rng.integers(96, 800))
     cfg = dict(nfeatures=int(rng.choice([30, 200, 500, 1000, 1500, 3000])), scaleFactor=float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0])),
-               nlevels=int(rng.integers(1, 9)), iniThFAST=int(rng.integers(8, 41)), minThFAST=int(rng.integers(2, 12)))
+               nlevels=int(rng.integers(1, 17)), iniThFAST=int(rng.integers(8, 41)), minThFAST=int(rng.integers(2, 12)))
     if cfg["minThFAST"] > cfg["iniThFAST"]:
         cfg["minThFAST"] = cfg["iniThFAST"]
     img = random_image(rng, H, W, synth)
