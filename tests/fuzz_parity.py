@@ -187,6 +187,85 @@ def fuzz_last_frame(pkg, oracle, synth, rng, log, cache):
     return ok
 
 
+def _random_bow(rng, desc):
+    """Stand-in for a DBoW2 FeatureVector: a random hash of descriptor bits into a random number of nodes (sparse, unordered ids)."""
+    nodes = int(rng.choice([8, 32, 128, 512]))
+    b0, b1 = int(rng.integers(0, 32)), int(rng.integers(0, 32))
+    ids = ((desc[:, b0].astype(np.int64) >> 2) * 2 + (desc[:, b1].astype(np.int64) >> 7)) % nodes
+    fv = {}
+    for i, nid in enumerate(ids):
+        fv.setdefault(int(nid) * 7 + 3, []).append(i)
+    return fv
+
+
+def fuzz_bow_and_triangulation(pkg, oracle, synth, rng, log, cache):
+    """SearchByBoW (keyframe->frame, keyframe<->keyframe) and SearchForTriangulation on random keypoint subsets, vocabulary
+    partitions, map-point masks, stereo coordinates and relative poses."""
+    if "frames" not in cache:
+        fuzz_match(pkg, oracle, synth, np.random.default_rng(0), log, cache)
+    (k0, d0), (k1, d1) = cache["frames"]
+    sf, offs = cache["sf"], cache["offs"]
+    sigma2 = (sf * sf).astype(np.float32)
+    s0 = np.sort(rng.choice(len(k0), int(rng.integers(1, len(k0) + 1)), replace=False))
+    s1 = np.sort(rng.choice(len(k1), int(rng.integers(1, len(k1) + 1)), replace=False))
+    ka, da, kb, db = k0[s0], d0[s0], k1[s1], d1[s1]
+    fva, fvb = _random_bow(rng, da), _random_bow(rng, db)
+    if rng.random() < 0.5:       # same hash on both sides: many shared nodes; otherwise mostly disjoint ones
+        st = rng.bit_generator.state
+        fva = _random_bow(rng, da); rng.bit_generator.state = st; fvb = _random_bow(rng, db)
+    mpa = (rng.random(len(ka)) < rng.choice([0.2, 0.8, 1.0])).astype(np.uint8)
+    mpb = (rng.random(len(kb)) < rng.choice([0.2, 0.8, 1.0])).astype(np.uint8)
+    check_ori = bool(rng.integers(0, 2))
+    ok = True
+    # keyframe -> frame (:273-469)
+    KF, F = pkg.KeyFrameView(ka, da, fva, sf, sigma2, has_mappoint=mpa), pkg.KeyFrameView(kb, db, fvb, sf, sigma2)
+    OKF, OF = oracle.OracleKeyFrame(ka, da, fva, sf, sigma2, has_mp=mpa), oracle.OracleKeyFrame(kb, db, fvb, sf, sigma2)
+    nn = float(rng.choice([0.6, 0.7, 0.9]))
+    m = pkg.ORBmatcher(nn, check_ori)
+    try:
+        n_gpu, m_gpu = m.SearchByBoW(KF, F)
+        n_ref, m_ref = oracle.search_by_bow(OKF, OF, nn, check_ori)
+        if not (n_gpu == n_ref and np.array_equal(m_gpu, m_ref)):
+            ok = False
+            log("BOW KF-F MISMATCH n=%d/%d" % (n_gpu, n_ref))
+        cache.setdefault("stats", {}).setdefault("bow_matches", []).append(n_ref)
+        # keyframe <-> keyframe (:839-979)
+        K2 = pkg.KeyFrameView(kb, db, fvb, sf, sigma2, has_mappoint=mpb)
+        O2 = oracle.OracleKeyFrame(kb, db, fvb, sf, sigma2, has_mp=mpb)
+        n_gpu, m_gpu = m.SearchByBoWKeyFrames(KF, K2)
+        n_ref, m_ref = oracle.search_by_bow_keyframes(OKF, O2, nn, check_ori)
+        if not (n_gpu == n_ref and np.array_equal(m_gpu, m_ref)):
+            ok = False
+            log("BOW KF-KF MISMATCH n=%d/%d" % (n_gpu, n_ref))
+        # SearchForTriangulation (:981-1222), pinhole
+        cam = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+        z = 5.0
+        dx, dy = offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]
+        ang = rng.normal(0, 0.002)
+        R1w, t1w = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+        R2w = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+        t2w = np.array([dx * z / cam[0] + rng.normal(0, 0.01), dy * z / cam[1] + rng.normal(0, 0.01), rng.choice([0.02, -0.02, 0.1])], np.float32)
+        Cw1 = np.zeros(3, np.float32)
+        ura = np.where(rng.random(len(ka)) < 0.5, ka["x"] - np.float32(9.0), np.float32(-1)).astype(np.float32)
+        urb = np.where(rng.random(len(kb)) < 0.5, kb["x"] - np.float32(9.0), np.float32(-1)).astype(np.float32)
+        mta = (rng.random(len(ka)) < 0.2).astype(np.uint8); mtb = (rng.random(len(kb)) < 0.2).astype(np.uint8)
+        T1 = pkg.KeyFrameView(ka, da, fva, sf, sigma2, u_right=ura, has_mappoint=mta)
+        T2 = pkg.KeyFrameView(kb, db, fvb, sf, sigma2, u_right=urb, has_mappoint=mtb)
+        P1 = oracle.OracleKeyFrame(ka, da, fva, sf, sigma2, u_right=ura, has_mp=mta)
+        P2 = oracle.OracleKeyFrame(kb, db, fvb, sf, sigma2, u_right=urb, has_mp=mtb)
+        only_stereo, coarse = bool(rng.random() < 0.25), bool(rng.random() < 0.3)
+        n_gpu, pairs_gpu = m.SearchForTriangulation(T1, T2, R1w, t1w, R2w, t2w, Cw1, cam, cam, bOnlyStereo=only_stereo, bCoarse=coarse)
+        n_ref, pairs_ref = oracle.search_for_triangulation(P1, P2, R1w, t1w, R2w, t2w, Cw1, cam, cam, only_stereo=only_stereo, coarse=coarse,
+                                                           check_ori=check_ori)
+        cache.setdefault("stats", {}).setdefault("triangulation_pairs", []).append(n_ref)
+        if not (n_gpu == n_ref and np.array_equal(pairs_gpu, pairs_ref)):
+            ok = False
+            log("TRIANGULATION MISMATCH n=%d/%d stereo=%s coarse=%s" % (n_gpu, n_ref, only_stereo, coarse))
+    finally:
+        m.close()
+    return ok
+
+
 def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), first=0, verbose=False):
     """Cases first .. first+n-1 of stream `seed`; every case draws from its own generator, so one case can be replayed alone."""
     bad, cache, t0 = 0, {}, time.time()
@@ -198,9 +277,10 @@ def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), fir
             ok2 = fuzz_match(pkg, oracle, synth, np.random.default_rng([seed, i, 1]), log, cache)
             ok3 = fuzz_last_frame(pkg, oracle, synth, np.random.default_rng([seed, i, 2]), log, cache)
             ok4 = fuzz_reuse(pkg, oracle, synth, np.random.default_rng([seed, i, 3]), log, cache)
-            if not (ok1 and ok2 and ok3 and ok4):
+            ok5 = fuzz_bow_and_triangulation(pkg, oracle, synth, np.random.default_rng([seed, i, 4]), log, cache)
+            if not (ok1 and ok2 and ok3 and ok4 and ok5):
                 log("   ^ case %d of seed %d" % (i, seed))
-            bad += (not ok1) + (not ok2) + (not ok3) + (not ok4)
+            bad += (not ok1) + (not ok2) + (not ok3) + (not ok4) + (not ok5)
             if (i + 1 - first) % 20 == 0:
                 log("%d / %d cases, %d mismatches, %.0f s" % (i + 1 - first, n, bad, time.time() - t0))
     finally:
@@ -224,7 +304,7 @@ def main():
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
     from oracle import oracle_py as oracle   # the checker
     bad = run(pkg, oracle, synth, args.n, args.seed, first=args.first, verbose=args.verbose)
-    print("fuzz: %d cases each of: extractor configuration, window search, last-frame search, handle reuse; %d mismatches" % (args.n, bad))
+    print("fuzz: %d cases each of: extractor configuration, window search, last-frame search, handle reuse, BoW x2 + triangulation; %d mismatches" % (args.n, bad))
     sys.exit(1 if bad else 0)
 
 
