@@ -31,10 +31,10 @@ ABI_SYMBOLS = [
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
-    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_calibration_copy", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
+    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -48,6 +48,11 @@ class KeyFrameStruct(C.Structure):  # orbm_keyframe_t
     _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
                 ("has_mappoint", C.c_void_p), ("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
                 ("node_idx", C.c_void_p), ("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p), ("nlevels", C.c_int32)]
+
+
+class LastFrameStruct(C.Structure):  # orbm_last_frame_t
+    _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("Xw", C.c_void_p), ("mpdesc", C.c_void_p), ("last_keys", C.c_void_p),
+                ("obs", C.c_void_p), ("Tcw", C.c_void_p), ("Tlw", C.c_void_p)]
 
 
 class QueryStruct(C.Structure):  # orbm_queries_t
@@ -100,6 +105,10 @@ def load(build_if_needed=True):
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
     L.orbx_calibration_copy.argtypes = [vp, vp, sz, vp]
+    L.orbx_calibration_valu_ops.argtypes = []
+    L.orbx_calibration_valu_name.restype = C.c_char_p
+    L.orbx_calibration_valu_name.argtypes = [i32]
+    L.orbx_calibration_valu.argtypes = [i32, i32, i32, i32, vp, vp, vp]
     L.orbx_compute_stereo_matches.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp]
     L.orbx_cvt_color_gray.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, sz]
     L.orbx_cvt_color_gray_device.argtypes = [vp, i32, i32, sz, i32, i32, vp, sz, vp]
@@ -111,6 +120,10 @@ def load(build_if_needed=True):
     L.orbx_ref_cosf.argtypes = [f32]
     L.orbx_ref_sinf.restype = f32
     L.orbx_ref_sinf.argtypes = [f32]
+    L.orbx_ref_atanf.restype = f32
+    L.orbx_ref_atanf.argtypes = [f32]
+    L.orbx_ref_atan2f.restype = f32
+    L.orbx_ref_atan2f.argtypes = [f32, f32]
     L.orbm_create.restype = vp
     L.orbm_create.argtypes = [i32]
     L.orbm_destroy.argtypes = [vp]
@@ -138,6 +151,8 @@ def load(build_if_needed=True):
     L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, i32, i32, vp, vp]
     L.orbm_search_by_projection_last_frame.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32,
                                                        i32, i32, vp, vp]
+    L.orbm_search_by_projection_last_frame_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, f32, f32, f32,
+                                                                    i32, i32, vp, vp, vp, vp, vp]
     L.orbm_three_maxima.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_radius_by_viewing_cos.restype = f32
     L.orbm_radius_by_viewing_cos.argtypes = [f32]

@@ -14,10 +14,13 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/orbhip.h"
 #include "orb_kernels.h"
 #include "orb_match_kernels.h"
+#include "orb_calib.h"
+#include "orb_project_kernels.h"
 
 static_assert(sizeof(orbx_keypoint_t) == 28, "cv::KeyPoint layout");
 static_assert(sizeof(KpOut) == 28, "cv::KeyPoint layout");
@@ -77,6 +80,7 @@ struct orbx_handle {
   // last call
   FrameParams last{};
   bool have_last = false;
+  hipEvent_t last_done = nullptr;   // recorded on the extraction's stream behind its last kernel
   DevBuf stereo[7];  // grow-only buffers of orbx_compute_stereo_matches
   DevBuf maps[2];    // rectification maps of orbx_remap_linear, kept between calls
   int maps_rows = 0, maps_cols = 0;
@@ -107,16 +111,45 @@ struct orbx_handle {
     }                                                                                         \
   } while (0)
 
+// The dynamic-LDS limit is an attribute of the kernel FUNCTION (per device), not of a handle or a launch: handles on
+// several host threads (Tracking / LocalMapping / LoopClosing each own a matcher, stereo runs two extractors) would race
+// a per-launch "set to this launch's size" against each other's launches.  It is raised once per device, to the CU's whole
+// 160 KiB, for every kernel that can ask for more than the 64 KiB default; launches only check their own size against it.
+#define ORB_LDS_LIMIT (160 * 1024)
+static hipError_t raise_lds_limits(int device) {
+  static std::mutex mu;
+  static bool done[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  if (done[device]) return hipSuccess;
+  const void *fns[] = {reinterpret_cast<const void *>(&k_octree<256, true>), reinterpret_cast<const void *>(&k_octree<256, false>),
+                       reinterpret_cast<const void *>(&k_resize),
+                       reinterpret_cast<const void *>(&k_match_resolve<Key32, true>), reinterpret_cast<const void *>(&k_match_resolve<Key32, false>),
+                       reinterpret_cast<const void *>(&k_match_resolve<Key64, true>), reinterpret_cast<const void *>(&k_match_resolve<Key64, false>)};
+  for (const void *fn : fns) {
+    hipFuncAttributes a;
+    hipError_t e = hipFuncGetAttributes(&a, fn);
+    if (e != hipSuccess) return e;
+    const int room = ORB_LDS_LIMIT - (int)a.sharedSizeBytes;   // static __shared__ of the kernel counts against the same 160 KiB
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, room);
+    if (e != hipSuccess) return e;
+  }
+  done[device] = true;
+  return hipSuccess;
+}
+
 extern "C" {
 
 float orbx_ref_cosf(float x) { return orbsc::ref_cosf(x); }
 float orbx_ref_sinf(float x) { return orbsc::ref_sinf(x); }
+float orbx_ref_atanf(float x) { return orbat::ref_atanf(x); }
+float orbx_ref_atan2f(float y, float x) { return orbat::ref_atan2f(y, x); }
 
 orbx_t *orbx_create(int nfeatures, float scaleFactor_, int nlevels, int iniThFAST, int minThFAST, int device) {
   if (nfeatures < 0 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scaleFactor_ > 1.0f)) return nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
-  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (hipSetDevice(device) != hipSuccess || raise_lds_limits(device) != hipSuccess) return nullptr;
   orbx_handle *h = new orbx_handle();
   h->device = device;
   h->nfeatures = nfeatures;
@@ -198,6 +231,7 @@ void orbx_destroy(orbx_t *h) {
   for (DevBuf &b : h->stereo) b.release();
   for (DevBuf &b : h->maps) b.release();
   if (h->graph) (void)hipGraphExecDestroy(h->graph);
+  if (h->last_done) (void)hipEventDestroy(h->last_done);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->ev_ok)
@@ -417,10 +451,7 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   h->octCellsLds = lds + 4 * ((size_t)maxCells + 1) <= 96 * 1024;
   if (h->octCellsLds) lds += 4 * ((size_t)maxCells + 1);
   h->octLds = lds;
-  if (lds > 48 * 1024) {
-    if (h->octCellsLds) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_octree<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  if (lds > ORB_LDS_LIMIT) { h->err = "octree LDS state exceeds 160 KiB"; return ORBX_E_ARG; }   // limit raised once in orbx_create
   h->rows = rows;
   h->cols = cols;
   h->max_batch = max_batch;
@@ -467,6 +498,9 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (!d_kps || !d_desc || !d_counts || cap <= 0 || stride < (size_t)cols) return ORBX_E_ARG;
   int rc = orbx_configure(h, rows, cols, std::max(nframes, h->rows == rows && h->cols == cols ? h->max_batch : 1));
   if (rc < 0) return rc;
+  // asynchronous: an overflow could not be reported, and d_counts feeds the matcher as a live count bounded by its frame stride,
+  // so a capacity below the octree's worst case is refused up front
+  if (cap < h->maxKeypoints) { h->err = "cap below orbx_configure()'s bound"; return ORBX_E_CAP; }
   XCHECK(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream_;  // verbatim: NULL is the device's default stream
   FrameParams P;
@@ -514,7 +548,6 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
     const size_t lds = align_up((size_t)((G.w + 3) & ~3) * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;   // x table padded to whole quads
-    if (lds > 48 * 1024) XCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
@@ -531,6 +564,9 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   XCHECK(h, hipGetLastError());
   h->last = P;
   h->have_last = true;
+  // consumers of this batch on OTHER streams (orbx_compute_stereo_matches, orbx_download_*) order themselves behind it
+  if (!h->last_done) XCHECK(h, hipEventCreateWithFlags(&h->last_done, hipEventDisableTiming));
+  XCHECK(h, hipEventRecord(h->last_done, s));
   return 0;
 }
 
@@ -630,6 +666,64 @@ int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *s
   if (!d_src || !d_dst || nbytes < 4) return ORBX_E_ARG;
   hipLaunchKernelGGL(k_calib_copy_u32, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_src, (uint32_t *)d_dst, nbytes / 4);
   return hipGetLastError() == hipSuccess ? 0 : ORBX_E_HIP;
+}
+
+// Vector-issue ceiling of one opcode class (orb_calib.h).  Synchronous; uses the device's default stream.
+int orbx_calibration_valu_ops(void) { return CAL_NUM_OPS; }
+const char *orbx_calibration_valu_name(int op) { return op >= 0 && op < CAL_NUM_OPS ? kCalibOpNames[op] : nullptr; }
+
+int orbx_calibration_valu(int device, int op, int waves_per_simd, int trips, double *wave_instr_per_s, double *cycles_per_instr,
+                          double *clock_ghz) {
+  if (op < 0 || op >= CAL_NUM_OPS || trips < 1 || trips > (1 << 20)) return ORBX_E_ARG;
+  if (waves_per_simd != 1 && waves_per_simd != 2 && waves_per_simd != 4 && waves_per_simd != 8) return ORBX_E_ARG;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return ORBX_E_HIP;
+  const int cus = prop.multiProcessorCount;
+  const int rounds = 4;                                               // every CU stays full until the last round drains
+  const int grid = cus * waves_per_simd * rounds;                     // 256 threads = one wavefront per SIMD of a CU
+  const size_t lds = (size_t)(160 * 1024 / waves_per_simd);           // => exactly waves_per_simd workgroups resident per CU
+  uint32_t *sink = nullptr;
+  unsigned long long *stamps = nullptr;
+  if (hipMalloc(&sink, 256 * sizeof(uint32_t)) != hipSuccess) return ORBX_E_HIP;
+  if (hipMalloc(&stamps, (size_t)grid * 2 * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(sink); return ORBX_E_HIP; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  float best = 1e30f;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = ORBX_E_HIP;
+  for (int rep = 0; rep < 4 && rc == 0; rep++) {                      // rep 0 warms the code object and the clocks
+    (void)hipEventRecord(e0, (hipStream_t)0);
+    if (calib_dispatch<0>(op, grid, lds, sink, stamps, trips) != hipSuccess) { rc = ORBX_E_HIP; break; }
+    (void)hipEventRecord(e1, (hipStream_t)0);
+    if (hipEventSynchronize(e1) != hipSuccess) { rc = ORBX_E_HIP; break; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  if (rc == 0) {
+    std::vector<unsigned long long> st((size_t)grid * 2);
+    if (hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = ORBX_E_HIP;
+    else {
+      // median over the workgroups that ran with the CU full (all but the last round)
+      std::vector<double> cyc, clk;
+      for (int b = 0; b < grid; b++) {
+        const double ticks = (double)st[2 * b], ref = (double)st[2 * b + 1];
+        if (ref <= 0) continue;
+        cyc.push_back(ticks / ((double)trips * CAL_INSTR_PER_TRIP * waves_per_simd));
+        clk.push_back(ticks / ref * 0.1);                             // s_memrealtime runs at 100 MHz
+      }
+      std::sort(cyc.begin(), cyc.end());
+      std::sort(clk.begin(), clk.end());
+      const double total = (double)grid * 4.0 * trips * CAL_INSTR_PER_TRIP;
+      if (wave_instr_per_s) *wave_instr_per_s = total / ((double)best * 1e-3);
+      if (cycles_per_instr) *cycles_per_instr = cyc.empty() ? 0.0 : cyc[cyc.size() / 2];
+      if (clock_ghz) *clock_ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  (void)hipFree(stamps);
+  return rc;
 }
 
 int orbx_cvt_color_gray_device(const uint8_t *d_src, int rows, int cols, size_t src_stride, int channels, int rgb_order, uint8_t *d_dst,
@@ -817,6 +911,7 @@ struct orbm_handle {
   hipStream_t stream = nullptr;
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   DevBuf d_partner, d_qside, d_qany;
+  DevBuf d_lfq;       // query arrays written by k_lastframe_project (orbm_search_by_projection_last_frame_batch_device)
   DevBuf d_block;     // inputs + outputs of one host-pointer search, one block (see search_host)
   void *pin = nullptr; size_t pin_bytes = 0;   // its pinned host mirror
   DevBuf scratch[8];  // grow-only buffers of the per-node / per-map-point entry points (SearchByBoW, ...)
@@ -848,7 +943,7 @@ extern "C" {
 orbm_t *orbm_create(int device) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
-  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (hipSetDevice(device) != hipSuccess || raise_lds_limits(device) != hipSuccess) return nullptr;
   orbm_handle *m = new orbm_handle();
   m->device = device;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return nullptr; }
@@ -861,7 +956,7 @@ void orbm_destroy(orbm_t *m) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
                     &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany, &m->scratch[0], &m->scratch[1], &m->scratch[2], &m->scratch[3],
-                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block};
+                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block, &m->d_lfq};
   for (DevBuf *b : bufs) b->release();
   if (m->pin) (void)hipHostFree(m->pin);
   if (m->ev_ok)
@@ -991,13 +1086,16 @@ void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float
     *v = p[1] * Y / Z + p[3];
   } else {  // KannalaBrandt8.cpp:29-45
     const float x2_plus_y2 = X * X + Y * Y;
-    const float theta = atan2f(sqrtf(x2_plus_y2), Z);
-    const float psi = atan2f(Y, X);
+    const float theta = orbat::ref_atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = orbat::ref_atan2f(Y, X);
     const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
                 theta9 = theta7 * theta2;
     const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
-    *u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);  // ::cos(double), see DESIGN.md
-    *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+    // cos / sin on a float resolve to the float overloads (cosf / sinf) once <math.h> is in the translation unit, which
+    // opencv2/opencv.hpp brings (libm choices) - the same assumption MapPoint::PredictScale's log(float) rests on;
+    // evaluated through the bit-exact glibc replicas the device uses (tests/test_libm_replicas.py: equal to the host libm)
+    *u = p[0] * r * orbsc::ref_cosf(psi) + p[2];
+    *v = p[1] * r * orbsc::ref_sinf(psi) + p[3];
   }
 }
 
@@ -1062,9 +1160,6 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const dim3 rblock(64 * RESOLVE_NW);
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
-    if (lds > 48 * 1024)                                                                                                  \
-      MCHECK(m, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_match_resolve<KT, LC>),                             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
     if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
     else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);  \
     else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);     \
@@ -1186,6 +1281,63 @@ static void mat3_mul_add(const float *R, const float *x, const float *t, float *
   }
 }
 
+int orbm_search_by_projection_last_frame_batch_device(orbm_t *m, const orbm_frame_t *cur0, int frame_stride, const int32_t *d_frame_n,
+                                                      int frame_n_stride, const orbm_last_frame_t *last0, int last_stride,
+                                                      const int32_t *d_last_n, int last_n_stride, int npairs, const float *sf, int nlevels,
+                                                      int cam_type, const float *cam_params, float mb, float mbf, float th, int bMono,
+                                                      int checkOri, int32_t *d_slot, uint8_t *d_slot_obs, int32_t *d_moq,
+                                                      int32_t *d_nmatches, void *stream_) {
+  if (!m || !cur0 || !last0 || !sf || !cam_params || npairs <= 0 || !d_slot || !d_slot_obs || !d_nmatches) return ORBX_E_ARG;
+  if (nlevels < 1 || nlevels > 16 || (cam_type != 0 && cam_type != 1)) return ORBX_E_ARG;
+  if (!last0->has_mp || !last0->Xw || !last0->mpdesc || !last0->last_keys || !last0->Tcw || !last0->Tlw) return ORBX_E_ARG;
+  const int maxq = d_last_n ? last_stride : last0->n;
+  if (maxq <= 0 || last_stride < maxq) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = (hipStream_t)stream_;
+  // scratch: the query arrays the projection kernel writes (29 B per query) - grows on demand, not on the steady-state path
+  const size_t nqa = (size_t)(npairs - 1) * last_stride + maxq, nq4 = (nqa + 63) & ~(size_t)63;
+  const size_t need = nq4 * (4 * sizeof(float) + 3 * sizeof(int32_t) + 1);
+  if (need > m->d_lfq.bytes) {
+    MCHECK(m, hipStreamSynchronize(s));
+    MCHECK(m, m->d_lfq.reserve(need + (need >> 2)));
+  }
+  float *qf = (float *)m->d_lfq.p;
+  int32_t *qi = (int32_t *)(qf + 4 * nq4);
+  uint8_t *qfl = (uint8_t *)(qi + 3 * nq4);
+  int32_t *moq = d_moq ? d_moq : qi + 2 * nq4;
+  LastFrameParams P;
+  memset(&P, 0, sizeof(P));
+  P.has_mp = last0->has_mp; P.Xw = last0->Xw; P.last_kp = reinterpret_cast<const float *>(last0->last_keys); P.obs = last0->obs;
+  P.Tcw = last0->Tcw; P.Tlw = last0->Tlw;
+  P.last_stride = last_stride; P.last_n = d_last_n; P.last_n_stride = last_n_stride; P.last_n_const = last0->n;
+  P.min_x = cur0->min_x; P.max_x = cur0->max_x; P.min_y = cur0->min_y; P.max_y = cur0->max_y;
+  for (int l = 0; l < nlevels; l++) P.sf[l] = sf[l];
+  P.nlevels = nlevels;
+  P.cam_type = cam_type;
+  for (int k = 0; k < (cam_type == 0 ? 4 : 8); k++) P.cam[k] = cam_params[k];
+  P.mb = mb; P.mbf = mbf; P.th = th; P.bMono = bMono ? 1 : 0;
+  P.qu = qf; P.qv = qf + nq4; P.qr = qf + 2 * nq4; P.qur = qf + 3 * nq4;
+  P.qminl = qi; P.qmaxl = qi + nq4; P.qflags = qfl;
+  hipLaunchKernelGGL(k_lastframe_project, dim3((last_stride + 255) / 256, npairs), dim3(256), 0, s, P);
+  orbm_queries_t q;
+  q.nq = last0->n; q.descriptors = last0->mpdesc; q.u = P.qu; q.v = P.qv; q.radius = P.qr;
+  q.min_level = P.qminl; q.max_level = P.qmaxl; q.u_r = cur0->u_right ? P.qur : nullptr; q.flags = P.qflags;
+  int rc = orbm_search_by_projection_batch_device(m, cur0, frame_stride, d_frame_n, frame_n_stride, &q, last_stride, d_last_n, last_n_stride, npairs,
+                                                  0.f, ORBM_TH_HIGH, 0, d_slot, d_slot_obs, moq, nullptr, d_nmatches, s);   // :2148-2162
+  if (rc < 0) return rc;
+  if (checkOri) {                                                                                                            // :2177-2185, :2263-2286
+    RotPruneParams R;
+    memset(&R, 0, sizeof(R));
+    R.last_kp = reinterpret_cast<const float *>(last0->last_keys);
+    R.last_stride = last_stride; R.last_n = d_last_n; R.last_n_stride = last_n_stride; R.last_n_const = last0->n;
+    R.cur_kp = reinterpret_cast<const float *>(cur0->keys_un); R.frame_stride = frame_stride;
+    R.moq = moq; R.slot = d_slot; R.slot_obs = d_slot_obs; R.nmatches = d_nmatches;
+    hipLaunchKernelGGL(k_rot_prune, dim3(npairs), dim3(256), 0, s, R);
+  }
+  MCHECK(m, hipGetLastError());
+  return 0;
+}
+
 int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, const float *sf, int nlevels, int nLast,
                                          const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
                                          const orbx_keypoint_t *last_keys, const uint8_t *obs, const float *Tcw,
@@ -1193,64 +1345,62 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
                                          float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs) {
   if (!m || !cur || !sf || nLast < 0 || !Tcw || !Tlw || !cam_params || !slot || !slot_obs) return ORBX_E_ARG;
   if (nLast > 0 && (!has_mp || !Xw || !mpdesc || !last_keys)) return ORBX_E_ARG;
-  const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]}, tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
-  float twc[3], tlc[3];
-  for (int i = 0; i < 3; i++) {  // twc = -Rcw.t()*tcw, :2041
-    double s = 0;
-    for (int k = 0; k < 3; k++) s += (double)Tcw[k * 4 + i] * (double)tcw[k];
-    twc[i] = (float)(s * -1.0);
+  if (nlevels < 1 || nlevels > 16) return ORBX_E_ARG;
+  const int n = cur->n;
+  if (n < 0) return ORBX_E_ARG;
+  if (n == 0 || nLast == 0) return 0;
+  if (!cur->keys_un || !cur->descriptors) return ORBX_E_ARG;
+  for (int i = 0; i < nLast; i++)
+    if (has_mp[i] && (last_keys[i].octave < 0 || last_keys[i].octave >= nlevels)) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  // one pinned block up, one block down, one synchronisation (as search_host); projection, search and pruning on the device
+  struct Part { const void *src; size_t bytes, off; };
+  size_t total = 0;
+  auto part = [&](const void *src, size_t bytes) { Part p{src, bytes, total}; total += (bytes + 255) & ~(size_t)255; return p; };
+  const Part pKp = part(cur->keys_un, sizeof(orbx_keypoint_t) * (size_t)n), pDesc = part(cur->descriptors, 32 * (size_t)n);
+  const Part pUr = part(cur->u_right, cur->u_right ? sizeof(float) * (size_t)n : 0);
+  const Part pHas = part(has_mp, (size_t)nLast), pXw = part(Xw, 3 * sizeof(float) * (size_t)nLast), pMd = part(mpdesc, 32 * (size_t)nLast);
+  const Part pLk = part(last_keys, sizeof(orbx_keypoint_t) * (size_t)nLast), pObs = part(obs, obs ? (size_t)nLast : 0);
+  const Part pTc = part(Tcw, 16 * sizeof(float)), pTl = part(Tlw, 16 * sizeof(float));
+  const size_t out_off = total;
+  const Part pSlot = part(slot, sizeof(int32_t) * (size_t)n), pSobs = part(slot_obs, (size_t)n);
+  const size_t upload_total = total;
+  const Part pNm = part(nullptr, sizeof(int32_t));
+  if (m->pin_bytes < total) {
+    if (m->pin) (void)hipHostFree(m->pin);
+    m->pin = nullptr; m->pin_bytes = 0;
+    MCHECK(m, hipHostMalloc(&m->pin, total + (total >> 2), hipHostMallocDefault));
+    m->pin_bytes = total + (total >> 2);
   }
-  mat3_mul_add(Tlw, twc, tlw, tlc);  // tlc = Rlw*twc+tlw, :2047
-  const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;  // :2051-2052
-  std::vector<float> u(nLast), v(nLast), rad(nLast), ur(nLast);
-  std::vector<int32_t> minl(nLast), maxl(nLast), moq(nLast);
-  std::vector<uint8_t> flags(nLast);
-  for (int i = 0; i < nLast; i++) {
-    flags[i] = 0; u[i] = v[i] = rad[i] = ur[i] = 0.f; minl[i] = maxl[i] = -1;
-    if (!has_mp[i]) continue;
-    float x3Dc[3];
-    mat3_mul_add(Tcw, Xw + 3 * i, tcw, x3Dc);                  // :2072
-    const float invzc = (float)(1.0 / (double)x3Dc[2]);        // :2076
-    if (invzc < 0) continue;
-    float ux, vy;
-    orbm_project(cam_type, cam_params, x3Dc[0], x3Dc[1], x3Dc[2], &ux, &vy);  // :2091
-    if (ux < cur->min_x || ux > cur->max_x) continue;          // :2094-2097
-    if (vy < cur->min_y || vy > cur->max_y) continue;
-    const int nLastOctave = last_keys[i].octave;
-    if (nLastOctave < 0 || nLastOctave >= nlevels) return ORBX_E_ARG;
-    u[i] = ux; v[i] = vy;
-    rad[i] = th * sf[nLastOctave];                             // :2105
-    if (bForward) { minl[i] = nLastOctave; maxl[i] = -1; }     // :2113-2118
-    else if (bBackward) { minl[i] = 0; maxl[i] = nLastOctave; }
-    else { minl[i] = nLastOctave - 1; maxl[i] = nLastOctave + 1; }
-    ur[i] = ux - mbf * invzc;                                  // :2141
-    flags[i] = (uint8_t)(1u | ((obs ? (obs[i] & 1u) : 1u) << 1));
-  }
-  orbm_queries_t q;
-  q.nq = nLast; q.descriptors = mpdesc; q.u = u.data(); q.v = v.data(); q.radius = rad.data();
-  q.min_level = minl.data(); q.max_level = maxl.data(); q.u_r = ur.data(); q.flags = flags.data();
-  int nmatches = orbm_search_by_projection(m, cur, &q, 0.f, ORBM_TH_HIGH, 0, slot, slot_obs, moq.data(), nullptr);
-  if (nmatches < 0 || !checkOri) return nmatches;
-  // rotation consistency, :2177-2185 and :2263-2286 (factor = 1/HISTO_LENGTH, so only bins 0..12 are reachable)
-  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
-  const float factor = 1.0f / ORBM_HISTO_LENGTH;
-  for (int i = 0; i < nLast; i++) {
-    if (moq[i] < 0) continue;
-    float rot = last_keys[i].angle - cur->keys_un[moq[i]].angle;
-    if ((double)rot < 0.0) rot += 360.0f;
-    int bin = (int)roundf(rot * factor);
-    if (bin == ORBM_HISTO_LENGTH) bin = 0;
-    if (bin < 0 || bin >= ORBM_HISTO_LENGTH) continue;
-    rotHist[bin].push_back(moq[i]);
-  }
-  int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
-  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
-  orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
-  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
-    if (i == ind1 || i == ind2 || i == ind3) continue;
-    for (int idx : rotHist[i]) { slot[idx] = -1; slot_obs[idx] = 0; nmatches--; }
-  }
-  return nmatches;
+  MCHECK(m, m->d_block.reserve(total + (total >> 2)));
+  uint8_t *hp = (uint8_t *)m->pin, *dp = (uint8_t *)m->d_block.p;
+  for (const Part *p : {&pKp, &pDesc, &pUr, &pHas, &pXw, &pMd, &pLk, &pObs, &pTc, &pTl, &pSlot, &pSobs})
+    if (p->bytes) memcpy(hp + p->off, p->src, p->bytes);
+  MCHECK(m, hipMemcpyAsync(dp, hp, upload_total, hipMemcpyHostToDevice, s));
+  orbm_frame_t df = *cur;
+  df.keys_un = (const orbx_keypoint_t *)(dp + pKp.off);
+  df.descriptors = dp + pDesc.off;
+  df.u_right = cur->u_right ? (const float *)(dp + pUr.off) : nullptr;
+  orbm_last_frame_t dl;
+  memset(&dl, 0, sizeof(dl));
+  dl.n = nLast;
+  dl.has_mp = dp + pHas.off; dl.Xw = (const float *)(dp + pXw.off); dl.mpdesc = dp + pMd.off;
+  dl.last_keys = (const orbx_keypoint_t *)(dp + pLk.off);
+  dl.obs = obs ? dp + pObs.off : nullptr;
+  dl.Tcw = (const float *)(dp + pTc.off); dl.Tlw = (const float *)(dp + pTl.off);
+  m->ext = {};
+  int rc = orbm_search_by_projection_last_frame_batch_device(m, &df, n, nullptr, 0, &dl, nLast, nullptr, 0, 1, sf, nlevels, cam_type, cam_params, mb, mbf,
+                                                             th, bMono, checkOri, (int32_t *)(dp + pSlot.off), dp + pSobs.off, nullptr,
+                                                             (int32_t *)(dp + pNm.off), s);
+  if (rc < 0) return rc;
+  MCHECK(m, hipMemcpyAsync(hp + out_off, dp + out_off, pNm.off + sizeof(int32_t) - out_off, hipMemcpyDeviceToHost, s));
+  MCHECK(m, hipStreamSynchronize(s));
+  memcpy(slot, hp + pSlot.off, pSlot.bytes);
+  memcpy(slot_obs, hp + pSobs.off, pSobs.bytes);
+  int32_t nm = 0;
+  memcpy(&nm, hp + pNm.off, sizeof(nm));
+  return nm;
 }
 
 static int prune_by_rotation(int nq, const int32_t *moq, const float *query_angle, const orbx_keypoint_t *keys, int32_t *slot,
@@ -1882,7 +2032,10 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
   if (!(mb > 0.f)) return ORBX_E_ARG;
   XCHECK(hl, hipSetDevice(hl->device));
   hipStream_t s = hl->stream;
-  XCHECK(hl, hipStreamSynchronize(hr->stream));
+  // the two extractions may have run on any stream (the handles' own, or the caller's with orbx_extract_batch_device): the
+  // search is ordered behind the last kernel of both; level 0 is read in place from the caller's images (orbhip.h)
+  if (hl->last_done) XCHECK(hl, hipStreamWaitEvent(s, hl->last_done, 0));
+  if (hr->last_done) XCHECK(hl, hipStreamWaitEvent(s, hr->last_done, 0));
   DevBuf *bufs = hl->stereo;
   const size_t sz[7] = {sizeof(orbx_keypoint_t) * (size_t)nL, sizeof(orbx_keypoint_t) * (size_t)nR, 32 * (size_t)nL, 32 * (size_t)nR,
                         sizeof(float) * (size_t)nL, sizeof(float) * (size_t)nL, sizeof(int32_t) * (size_t)nL};

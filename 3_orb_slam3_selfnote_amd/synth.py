@@ -125,3 +125,61 @@ def make_descriptor_sets(seed, n=1000, flip_p=0.08, fresh_frac=0.2):
     is_fresh = s.ints(n, 0, 999) < int(round(fresh_frac * 1000))
     q[is_fresh] = fresh[is_fresh]
     return np.ascontiguousarray(q), np.ascontiguousarray(cand)
+
+
+# Examples/Monocular/TUM_512.yaml:9-19 (BASELINE config 5): KannalaBrandt8 fx, fy, cx, cy, k1..k4
+TUMVI_KB8 = np.array([190.978477, 190.973307, 254.931706, 256.897442, 0.003482389402, 0.000715034845, -0.002053236141, 0.000202936736],
+                     dtype=np.float32)
+
+
+def kb8_unproject(params, u, v):
+    """Unit rays of pixels (u, v) under the KannalaBrandt8 model [fx, fy, cx, cy, k0..k3]: r(theta) = theta + k0 theta^3 + ... is
+    inverted by Newton iterations in float64.  Scene construction only (the callers project the points back with the code under
+    test); it does not restate KannalaBrandt8::unproject."""
+    p = np.asarray(params, dtype=np.float64)
+    x = (np.asarray(u, np.float64) - p[2]) / p[0]
+    y = (np.asarray(v, np.float64) - p[3]) / p[1]
+    r = np.sqrt(x * x + y * y)
+    th = r.copy()
+    for _ in range(12):
+        t2 = th * th
+        f = th * (1 + t2 * (p[4] + t2 * (p[5] + t2 * (p[6] + t2 * p[7])))) - r
+        df = 1 + t2 * (3 * p[4] + t2 * (5 * p[5] + t2 * (7 * p[6] + t2 * 9 * p[7])))
+        th = th - f / df
+    s = np.where(r > 1e-12, np.sin(th) / np.maximum(r, 1e-12), 1.0)
+    return np.stack([x * s, y * s, np.cos(th)], axis=-1)
+
+
+def pinhole_unproject(params, u, v):
+    p = np.asarray(params, dtype=np.float64)
+    x = (np.asarray(u, np.float64) - p[2]) / p[0]
+    y = (np.asarray(v, np.float64) - p[3]) / p[1]
+    d = np.stack([x, y, np.ones_like(x)], axis=-1)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def make_last_frame_scene(cam_type, params, kx, ky, shift, seed, tz=0.0):
+    """Map points for a last-frame projection search (ORBmatcher.cc:2027-2289) over a shifted synthetic stream: the keypoint of
+    the last frame at (kx, ky) is seen at (kx, ky) + shift in the current frame, so its map point is placed on the CURRENT
+    camera's ray through that pixel (un-projected through the camera model under test, depth 2-9 m) and moved to the world
+    by the inverse of a small rigid current pose Tcw; Tlw = I.  Returns (Xw [n,3] f32, Tcw [4,4] f32, Tlw [4,4] f32).
+    Projecting Tcw * Xw with the model lands within float rounding of the shifted pixel, wherever it lies in the field of view."""
+    n = len(kx)
+    r = splitmix64(seed ^ 0xA24BAED4963EE407, np.arange(n + 8, dtype=np.uint64))
+    depth = 2.0 + (r[:n] % np.uint64(7001)).astype(np.float64) / 1000.0
+    ang = (-0.02 + (float(r[n] % np.uint64(4001)) / 1e5), -0.02 + (float(r[n + 1] % np.uint64(4001)) / 1e5), -0.03 + (float(r[n + 2] % np.uint64(6001)) / 1e5))
+    ca, sa, cb, sb, cg, sg = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+    R = (Rz @ Ry @ Rx).astype(np.float32).astype(np.float64)
+    t = np.array([0.05 - float(r[n + 3] % np.uint64(101)) / 1e3, -0.04 + float(r[n + 4] % np.uint64(81)) / 1e3, tz], dtype=np.float32).astype(np.float64)
+    u = np.asarray(kx, np.float64) + float(shift[0])
+    v = np.asarray(ky, np.float64) + float(shift[1])
+    rays = kb8_unproject(params, u, v) if cam_type == 1 else pinhole_unproject(params, u, v)
+    Xc = rays * depth[:, None]
+    Xw = (Xc - t[None, :]) @ R            # R^T (Xc - t), row-vector form
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = R.astype(np.float32)
+    Tcw[:3, 3] = t.astype(np.float32)
+    return np.ascontiguousarray(Xw.astype(np.float32)), Tcw, np.eye(4, dtype=np.float32)

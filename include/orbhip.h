@@ -79,7 +79,10 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
 /* Batched, device-resident form of the same call: frame f is at d_images + f*frame_stride.
  * d_keypoints: [nframes][cap] orbx_keypoint_t, d_descriptors: [nframes][cap][32], d_counts: [nframes][2] int32 =
  * {n, monoIndex}.  All device pointers; asynchronous on `stream`.  The level-0 image of each frame is read in
- * place, so d_images must stay valid until the stream has drained. */
+ * place, so d_images must stay valid until the stream has drained - and for as long as orbx_compute_stereo_matches or
+ * orbx_download_level(level 0) may still be called for this batch (both order themselves behind the batch's last kernel
+ * with an event, whatever stream it ran on).  cap must be >= orbx_configure()'s return value (ORBX_E_CAP otherwise: an
+ * overflow could not be reported asynchronously, and d_counts is what the batched matcher takes as live counts). */
 int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int cols, size_t stride,
                               size_t frame_stride, int nframes, int lap0, int lap1, orbx_keypoint_t *d_keypoints,
                               uint8_t *d_descriptors, int32_t *d_counts, int cap, void *stream);
@@ -112,10 +115,26 @@ int orbx_get_stage_ms(orbx_t *h, float *ms, int cap);
  * pattern (tools/collect_traffic.py). */
 int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *stream);
 
+/* Measurement aid: the chip's vector-issue ceiling for one opcode class (csrc/orb_calib.h), the counterpart of
+ * orbx_calibration_copy for bench.py's `valu_issue` roofline.  Runs a stream of independent instructions of class `op`
+ * (0 <= op < orbx_calibration_valu_ops(); orbx_calibration_valu_name(op) names it) on every CU with `waves_per_simd` (1, 2, 4
+ * or 8) resident wavefronts per SIMD, `trips` x 128 instructions per wavefront.  Out: wave-instructions per second of the
+ * whole chip (HIP events), shader cycles one wave-instruction occupies its SIMD (s_memtime, median over workgroups) and the
+ * shader clock held meanwhile in GHz (s_memtime / s_memrealtime).  Synchronous, default stream.  tools/collect_valu_calib.py
+ * sweeps it into profiles/valu_calib.json. */
+int orbx_calibration_valu_ops(void);
+const char *orbx_calibration_valu_name(int op);
+int orbx_calibration_valu(int device, int op, int waves_per_simd, int trips, double *wave_instr_per_s, double *cycles_per_instr,
+                          double *clock_ghz);
+
 /* Device replica of the libm cosf/sinf the reference calls at ORBextractor.cc:111, exposed for the exhaustive
  * host-side check in tests (host evaluation of the same source the kernel compiles). */
 float orbx_ref_cosf(float x);
 float orbx_ref_sinf(float x);
+/* Likewise the device replicas of glibc's atanf / atan2f (fdlibm single precision) used by the on-device
+ * KannalaBrandt8::project (KannalaBrandt8.cpp:31-32), csrc/orb_atan2f.h. */
+float orbx_ref_atanf(float x);
+float orbx_ref_atan2f(float y, float x);
 
 /* cv::cvtColor(im, gray, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY) of Tracking::GrabImageMonocular / Stereo / RGBD
  * (Tracking.cc:1122-1135) for 8-bit input: channels = 3 or 4, rgb_order != 0 for RGB(A), 0 for BGR(A).
@@ -232,14 +251,39 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *frame0
  * (octave) / mvKeysUn[i] (angle); obs[i] = pMP->Observations()>0 (NULL = all 1).
  * Tcw / Tlw = CurrentFrame.mTcw / LastFrame.mTcw, row-major 4x4.  cam_type/cam_params: CurrentFrame.mpCamera
  * (see orbm_project).  mb, mbf: CurrentFrame.mb / mbf.  scale_factors = CurrentFrame.mvScaleFactors.
- * The projection (:2072-2097), window selection (:2105-2118) and the rotation-histogram pruning (:2177-2185,
- * :2263-2286) run on the host in fp32 exactly as written in the reference; the Hamming search with its sequential
- * claims runs on the device.  slot / slot_obs as in orbm_search_by_projection.  Returns nmatches. */
+ * One upload, then projection (:2072-2097), window selection (:2105-2118), the Hamming search with its sequential claims and
+ * the rotation-histogram pruning (:2177-2185, :2263-2286) all run on the device (see the batched form below), one download.
+ * slot / slot_obs as in orbm_search_by_projection.  Returns nmatches. */
 int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, const float *scale_factors, int nlevels,
                                          int nLast, const uint8_t *has_mp, const float *Xw, const uint8_t *mpdesc,
                                          const orbx_keypoint_t *last_keys, const uint8_t *obs, const float *Tcw,
                                          const float *Tlw, int cam_type, const float *cam_params, float mb, float mbf,
                                          float th, int bMono, int checkOri, int32_t *slot, uint8_t *slot_obs);
+
+/* Batched device form of the same member: `npairs` independent (current frame, last frame) problems, everything resident in
+ * HBM, asynchronous on `stream`, nothing touches the host.  Projection (:2038-2118, Pinhole or KannalaBrandt8 with bit-exact
+ * replicas of the libm calls), Hamming search with sequential claims (:2120-2162) and rotation pruning (:2177-2185, :2263-2286)
+ * are three kernels + the two search kernels.  Problem p reads the keypoint-indexed arrays of the current frame at element
+ * offset p * frame_stride (live counts d_frame_n[p * frame_n_stride], or cur0->n when d_frame_n is NULL) and the arrays of
+ * orbm_last_frame_t at element offset p * last_stride (live counts d_last_n[p * last_n_stride] or last0->n); Tcw / Tlw hold
+ * 16 floats per problem.  scale_factors / cam_params are HOST arrays (copied into the kernel arguments).
+ * d_slot / d_slot_obs [npairs][frame_stride] in/out as in orbm_search_by_projection; d_match_of_query [npairs][last_stride]
+ * (out, may be NULL) = current-frame keypoint matched by last-frame keypoint i after pruning, or -1; d_nmatches[npairs] out. */
+typedef struct {
+  int32_t n;                        /* nLast when d_last_n is NULL */
+  const uint8_t *has_mp;            /* LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] */
+  const float *Xw;                  /* 3 floats per keypoint */
+  const uint8_t *mpdesc;            /* 32 bytes per keypoint */
+  const orbx_keypoint_t *last_keys; /* octave (mvKeys) and angle (mvKeysUn: the same value) */
+  const uint8_t *obs;               /* or NULL = all 1 */
+  const float *Tcw, *Tlw;           /* row-major 4x4 per problem */
+} orbm_last_frame_t;
+int orbm_search_by_projection_last_frame_batch_device(orbm_t *m, const orbm_frame_t *cur0, int frame_stride, const int32_t *d_frame_n,
+                                                      int frame_n_stride, const orbm_last_frame_t *last0, int last_stride,
+                                                      const int32_t *d_last_n, int last_n_stride, int npairs, const float *scale_factors,
+                                                      int nlevels, int cam_type, const float *cam_params, float mb, float mbf, float th,
+                                                      int bMono, int checkOri, int32_t *d_slot, uint8_t *d_slot_obs,
+                                                      int32_t *d_match_of_query, int32_t *d_nmatches, void *stream);
 
 /* The same two members for a fisheye-stereo frame (Frame::Nleft != -1): ORBmatcher.cc:44-214 with its second half
  * (:145-211, right camera) and ORBmatcher.cc:2027-2289 with its extra pass (:2189-2256).

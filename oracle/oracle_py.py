@@ -14,7 +14,7 @@ _LIB = os.path.join(_HERE, "liborb_oracle.so")
 
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB) for f in ("orb_oracle.c", "orb_oracle.h")):
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB) for f in ("orb_oracle.c", "orb_oracle.h", "orb_cpu_bench.c", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
 
@@ -539,3 +539,49 @@ def remap_linear(im, mapx, mapy):
     if rc != 0:
         raise ValueError("orc_remap_linear rc=%d" % rc)
     return out
+
+
+class BenchCfg(C.Structure):  # orc_bench_cfg (orb_cpu_bench.c)
+    _fields_ = [("nframes", C.c_int), ("count", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("threads", C.c_int), ("warmup", C.c_int),
+                ("lap0", C.c_int), ("lap1", C.c_int), ("cap", C.c_int), ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int),
+                ("cam_type", C.c_int), ("cam", C.c_void_p), ("Xw", C.c_void_p), ("has_mp", C.c_void_p), ("Tcw", C.c_void_p), ("Tlw", C.c_void_p),
+                ("th", C.c_float), ("check_ori", C.c_int), ("bounds", C.c_float * 4)]
+
+
+def bench_stream(ex, frames, offs, count, threads=1, warmup=50, lap=(0, 1000), cap=None, mode=0, nnratio=0.8, th_high=100, scene=None):
+    """BASELINE.md section 3 protocol over the oracle, natively timed (orb_cpu_bench.c): frames [n, H, W] uint8, offs [n, 2] int32.
+    mode 0 = extract + config-3 stress match; mode 1 = extract + last-frame search with `scene` = dict(cam_type, cam, Xw [n, cap, 3],
+    has_mp [n, cap], Tcw [n, 16], Tlw [n, 16], th, check_ori, bounds).  Returns a dict with the per-frame outputs and times."""
+    L = lib()
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, H, W = frames.shape
+    offs = np.ascontiguousarray(offs, dtype=np.int32)
+    if cap is None:
+        cap = ex.nfeatures + 3 * ex.nlevels + 64
+    cfg = BenchCfg()
+    cfg.nframes, cfg.count, cfg.rows, cfg.cols, cfg.threads, cfg.warmup = n, int(count), H, W, int(threads), int(warmup)
+    cfg.lap0, cfg.lap1, cfg.cap, cfg.mode, cfg.nnratio, cfg.th_high = int(lap[0]), int(lap[1]), int(cap), int(mode), float(nnratio), int(th_high)
+    keep = []
+    if mode == 1:
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        cam, Xw, has, Tcw, Tlw = a(scene["cam"], np.float32), a(scene["Xw"], np.float32), a(scene["has_mp"], np.uint8), a(scene["Tcw"], np.float32), a(scene["Tlw"], np.float32)
+        assert Xw.shape == (n, cap, 3) and has.shape == (n, cap) and Tcw.shape == (n, 16) and Tlw.shape == (n, 16)
+        keep = [cam, Xw, has, Tcw, Tlw]
+        cfg.cam_type, cfg.cam, cfg.Xw, cfg.has_mp, cfg.Tcw, cfg.Tlw = int(scene["cam_type"]), cam.ctypes.data, Xw.ctypes.data, has.ctypes.data, Tcw.ctypes.data, Tlw.ctypes.data
+        cfg.th, cfg.check_ori = float(scene["th"]), int(scene["check_ori"])
+        for i, b in enumerate(scene["bounds"]):
+            cfg.bounds[i] = float(b)
+    kps = np.zeros((n, cap), dtype=KP_DTYPE)
+    desc = np.zeros((n, cap, 32), dtype=np.uint8)
+    counts = np.zeros((n, 2), dtype=np.int32)
+    moq = np.full((n, cap), -1, dtype=np.int32)
+    nmatch = np.zeros(n, dtype=np.int32)
+    ms_e, ms_m, wall = np.zeros(n), np.zeros(n), np.zeros(2)
+    L.orc_bench_stream.argtypes = [C.c_void_p] * 12
+    rc = L.orc_bench_stream(C.byref(ex.e), C.byref(cfg), _p(frames), _p(offs), _p(kps), _p(desc), _p(counts), _p(moq), _p(nmatch), _p(ms_e), _p(ms_m), _p(wall))
+    if rc != 0:
+        raise RuntimeError("orc_bench_stream rc=%d" % rc)
+    del keep
+    c = int(count)
+    return dict(kps=kps, desc=desc, counts=counts, moq=moq, nmatch=nmatch, ms_extract=ms_e[:c], ms_match=ms_m[:c], wall_extract=float(wall[0]),
+                wall_match=float(wall[1]), count=c, threads=int(threads), cap=int(cap))

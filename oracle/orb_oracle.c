@@ -22,6 +22,51 @@ static int cvCeil_(double v) { return (int)ceil(v); }
 
 float orc_libm_cosf(float x) { return cosf(x); }
 float orc_libm_sinf(float x) { return sinf(x); }
+float orc_libm_atanf(float x) { return atanf(x); }
+float orc_libm_atan2f(float y, float x) { return atan2f(y, x); }
+
+/* Native sweeps for tests/test_libm_replicas.py: the product's device-side replicas of cosf / sinf / atanf / atan2f (passed in
+ * as function pointers; evaluated on the host from the same source the kernels compile) against THIS host's libm.
+ * which: 0 cosf, 1 sinf, 2 atanf; bit patterns lo..hi (inclusive) in steps of `step`, both signs when both_signs.
+ * Returns the number of mismatching results (NaN inputs skipped). */
+long orc_sweep_unary(float (*replica)(float), int which, uint32_t lo, uint32_t hi, uint32_t step, int both_signs) {
+  long bad = 0;
+  if (step == 0) step = 1;
+  for (uint64_t u = lo; u <= hi; u += step) {
+    for (int sg = 0; sg <= (both_signs ? 1 : 0); sg++) {
+      const uint32_t b = (uint32_t)u | (sg ? 0x80000000u : 0u);
+      float x, a, r;
+      memcpy(&x, &b, 4);
+      if (x != x) continue;
+      a = which == 0 ? cosf(x) : which == 1 ? sinf(x) : atanf(x);
+      r = replica(x);
+      if (memcmp(&a, &r, 4) != 0) bad++;
+    }
+  }
+  return bad;
+}
+/* n random pairs (xorshift64*, seeded): odd draws are raw bit patterns (all magnitudes, infinities, zeros, denormals),
+ * even draws camera-like coordinates in [-scale, scale]. */
+long orc_sweep_atan2f(float (*replica)(float, float), uint64_t seed, long n, float scale) {
+  long bad = 0;
+  uint64_t s = seed ? seed : 88172645463325252ull;
+  for (long i = 0; i < n; i++) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    float y, x, a, r;
+    if (i & 1) {
+      uint32_t by = (uint32_t)s, bx = (uint32_t)(s >> 32);
+      memcpy(&y, &by, 4); memcpy(&x, &bx, 4);
+    } else {
+      y = (float)((double)(int32_t)(uint32_t)s / 2147483648.0 * (double)scale);
+      x = (float)((double)(int32_t)(uint32_t)(s >> 32) / 2147483648.0 * (double)scale);
+    }
+    if (x != x || y != y) continue;
+    a = atan2f(y, x);
+    r = replica(y, x);
+    if (memcmp(&a, &r, 4) != 0) bad++;
+  }
+  return bad;
+}
 
 static const int8_t kPattern[1024] = {
 #include "../include/orb_pattern_data.inc"
@@ -176,19 +221,31 @@ void orc_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_
   int k[7];
   orc_gauss7_kernel(k);
   uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)w * h);
+  const uint32_t k0 = (uint32_t)k[0], k1 = (uint32_t)k[1], k2 = (uint32_t)k[2], k3 = (uint32_t)k[3], k4 = (uint32_t)k[4], k5 = (uint32_t)k[5],
+                 k6 = (uint32_t)k[6];
+  /* row pass: the interior without the border arithmetic (same sums, same order), the 3 + 3 edge columns through reflect101 */
   for (int y = 0; y < h; y++) {
     const uint8_t *S = src + (size_t)y * sstride;
+    uint32_t *T = tmp + (size_t)y * w;
     for (int x = 0; x < w; x++) {
+      if (x == 3 && w > 6) {
+        for (; x < w - 3; x++)
+          T[x] = k0 * S[x - 3] + k1 * S[x - 2] + k2 * S[x - 1] + k3 * S[x] + k4 * S[x + 1] + k5 * S[x + 2] + k6 * S[x + 3];
+        x--;
+        continue;
+      }
       uint32_t s = 0;
       for (int i = 0; i < 7; i++) s += (uint32_t)k[i] * S[reflect101(x + i - 3, w)];
-      tmp[(size_t)y * w + x] = s;
+      T[x] = s;
     }
   }
+  /* column pass: seven row pointers per output row */
   for (int y = 0; y < h; y++) {
     uint8_t *D = dst + (size_t)y * dstride;
+    const uint32_t *R[7];
+    for (int j = 0; j < 7; j++) R[j] = tmp + (size_t)reflect101(y + j - 3, h) * w;
     for (int x = 0; x < w; x++) {
-      uint32_t s = 0;
-      for (int j = 0; j < 7; j++) s += (uint32_t)k[j] * tmp[(size_t)reflect101(y + j - 3, h) * w + x];
+      uint32_t s = k0 * R[0][x] + k1 * R[1][x] + k2 * R[2][x] + k3 * R[3][x] + k4 * R[4][x] + k5 * R[5][x] + k6 * R[6][x];
       uint32_t v = (s + 32768u) >> 16;
       D[x] = (uint8_t)(v > 255 ? 255 : v);
     }
@@ -943,10 +1000,14 @@ void orc_project(int type, const float *p, float X, float Y, float Z, float *u, 
     const float theta7 = theta5 * theta2;
     const float theta9 = theta7 * theta2;
     const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
-    /* un-suffixed cos/sin on a float in a TU without `using namespace std` -> ::cos(double)
-     * (hard part 7); the products are then evaluated in double. */
-    *u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
-    *v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+    /* Un-suffixed cos / sin on a float.  KannalaBrandt8.cpp has no `using namespace std`, so the overload depends on whether
+     * the C++ <math.h> wrapper (libstdc++ >= 6: `using std::cos;` -> float overloads in the global namespace) is in the
+     * translation unit.  It is: KannalaBrandt8.h -> TwoViewReconstruction.h:22 includes <opencv2/opencv.hpp>, whose FLANN
+     * headers include <math.h>.  The same closure is what makes `log(ratio)` in MapPoint::PredictScale (MapPoint.cc:578, :595;
+     * restated with logf below) a float call.  Hence cosf / sinf and float products.  (With GCC 5 or a libc++ without the
+     * wrapper this would be ::cos(double): an ambiguity of the reference's build, stated in DESIGN.md.) */
+    *u = p[0] * r * cosf(psi) + p[2];
+    *v = p[1] * r * sinf(psi) + p[3];
   }
 }
 

@@ -90,6 +90,11 @@ int orc_extract(const orc_extractor *e, const uint8_t *img, int rows, int cols, 
  * the product's replica against the host libm. */
 float orc_libm_cosf(float x);
 float orc_libm_sinf(float x);
+float orc_libm_atanf(float x);
+float orc_libm_atan2f(float y, float x);
+/* Sweeps of a replica (function pointer) against this host's libm; see orb_oracle.c.  Return the mismatch count. */
+long orc_sweep_unary(float (*replica)(float), int which, uint32_t lo, uint32_t hi, uint32_t step, int both_signs);
+long orc_sweep_atan2f(float (*replica)(float, float), uint64_t seed, long n, float scale);
 
 /* --- matcher ---------------------------------------------------------------------- */
 /* ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483. */

@@ -1,0 +1,189 @@
+"""GPU: (1) the getter tables of ORBextractor.h:61-83 (X9) - product vs oracle, bit patterns; (2) the reference's threading
+contract: two extractor INSTANCES run concurrently on two std::threads for stereo (Frame.cc:120-123,
+:1156-1159), matcher instances are used from three threads at once (Tracking, LocalMapping, LoopClosing: System.cc:193, 208,
+214).  ctypes releases the GIL around every C-ABI call, so Python threads enter liborbhip.so concurrently."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import EUROC, TUMVI
+
+pytestmark = pytest.mark.gpu
+
+INI5000 = dict(nfeatures=5000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)       # Tracking.cc:843-844: 5 * nFeatures
+KITTI = dict(nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)         # Examples/Monocular/KITTI00-02.yaml
+ODD = dict(nfeatures=777, scaleFactor=1.37, nlevels=5, iniThFAST=15, minThFAST=5)           # a non-1.2 factor, odd quota
+DEEP = dict(nfeatures=1200, scaleFactor=1.1, nlevels=12, iniThFAST=20, minThFAST=7)
+
+
+@pytest.mark.parametrize("cfg", [EUROC, TUMVI, INI5000, KITTI, ODD, DEEP], ids=["euroc", "tumvi", "ini5000", "kitti", "sf1.37", "sf1.1x12"])
+def test_getter_tables_equal_oracle(pkg, oracle, cfg):
+    """GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+    GetInverseScaleSigmaSquares (ORBextractor.h:61-81) and mnFeaturesPerLevel (ORBextractor.cc:432-444)."""
+    e = pkg.ORBextractor(**cfg)
+    o = oracle.OracleExtractor(**cfg)
+    nl = cfg["nlevels"]
+    try:
+        assert e.GetLevels() == nl == o.e.nlevels
+        assert np.float32(e.GetScaleFactor()).view(np.uint32) == np.float32(o.e.scaleFactor).view(np.uint32)
+        ref = {"GetScaleFactors": o.e.mvScaleFactor, "GetInverseScaleFactors": o.e.mvInvScaleFactor,
+               "GetScaleSigmaSquares": o.e.mvLevelSigma2, "GetInverseScaleSigmaSquares": o.e.mvInvLevelSigma2}
+        for name, table in ref.items():
+            got = getattr(e, name)()
+            want = np.array(table[:nl], dtype=np.float32)
+            assert got.dtype == np.float32 and len(got) == nl
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        assert e.features_per_level() == list(o.e.mnFeaturesPerLevel[:nl])
+        assert sum(e.features_per_level()) >= cfg["nfeatures"] - nl      # geometric series + remainder on the last level
+    finally:
+        e.close()
+
+
+def test_getter_constants_of_the_survey(pkg):
+    """The quotas SURVEY.md 8a derives independently from ORBextractor.cc:432-444."""
+    for cfg, want in ((EUROC, [217, 181, 151, 126, 105, 87, 73, 60]), (TUMVI, [326, 271, 226, 189, 157, 131, 109, 91]),
+                      (INI5000, [1086, 905, 754, 628, 524, 436, 364, 303])):
+        e = pkg.ORBextractor(**cfg)
+        assert e.features_per_level() == want
+        e.close()
+
+
+def _run_threads(fns):
+    errs = []
+
+    def wrap(f):
+        def g():
+            try:
+                f()
+            except BaseException as ex:  # noqa: BLE001 - reported to the main thread
+                errs.append(ex)
+        return g
+    ts = [threading.Thread(target=wrap(f)) for f in fns]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+def test_two_extractors_on_two_threads(pkg, frame):
+    """Frame.cc:120-123: thread threadLeft(&Frame::ExtractORB, this, 0, imLeft, ...), threadRight(..., 1, imRight, ...).
+    Two instances, different images (and different sizes in the second half, so that the two handles reconfigure while the
+    other one is running), 50 iterations, every result byte-equal to the sequential run."""
+    imgs = [frame(1000), frame(1001), frame(2000, 512, 512), frame(1002)[:400, :600].copy()]
+    left, right = pkg.ORBextractor(**EUROC), pkg.ORBextractor(**EUROC)
+    laps = [(0, 0), (0, 1000)]
+    try:
+        ref = {}
+        for i, im in enumerate(imgs):
+            for lap in laps:
+                mono, k, d = left(im, None, lap)
+                ref[(i, lap)] = (mono, k.tobytes(), d.tobytes())
+                mono2, k2, d2 = right(im, None, lap)
+                assert (mono2, k2.tobytes(), d2.tobytes()) == ref[(i, lap)]            # the two instances agree sequentially
+        bad = []
+
+        def worker(ex, order):
+            def run():
+                for it in range(50):
+                    i = order[it % len(order)]
+                    lap = laps[it % 2]
+                    mono, k, d = ex(imgs[i], None, lap)
+                    if (mono, k.tobytes(), d.tobytes()) != ref[(i, lap)]:
+                        bad.append((it, i, lap))
+            return run
+        _run_threads([worker(left, [0, 1, 0, 2, 3]), worker(right, [1, 0, 3, 3, 2, 0])])
+        assert not bad, bad[:5]
+    finally:
+        left.close(); right.close()
+
+
+def test_three_matchers_on_three_threads(pkg, oracle, synth):
+    """System.cc:193-214: Tracking, LocalMapping and LoopClosing each construct ORBmatcher objects and search at the same time.
+    Three handles, three different problems (sizes on both sides of the LDS-resident / global and Key32 / Key64 variants of the
+    resolve kernel), 50 iterations each, index-exact against the sequential run; one problem is also checked against the oracle."""
+    rng = np.random.default_rng(5)
+    sf = np.array([1.2 ** i for i in range(8)], dtype=np.float32)
+
+    def problem(N, nq, seed):
+        r = np.random.default_rng(seed)
+        kps = np.zeros(N, dtype=pkg.KP_DTYPE)
+        kps["x"] = r.uniform(5, 747, N).astype(np.float32)
+        kps["y"] = r.uniform(5, 475, N).astype(np.float32)
+        kps["octave"] = r.integers(0, 8, N)
+        base = r.integers(0, 256, (60, 32), dtype=np.uint8)
+        desc = base[r.integers(0, 60, N)].copy()
+        desc[r.random((N, 32)) < 0.03] ^= 4
+        qi = r.integers(0, N, nq)
+        return dict(kps=kps, desc=desc, qdesc=desc[qi].copy(), u=(kps["x"][qi] + r.uniform(-3, 3, nq)).astype(np.float32),
+                    v=(kps["y"][qi] + r.uniform(-3, 3, nq)).astype(np.float32), radius=r.choice(np.array([8.0, 30.0, 300.0], np.float32), nq),
+                    minl=np.full(nq, -1, np.int32), maxl=np.full(nq, -1, np.int32))
+
+    probs = [problem(900, 700, 1), problem(2500, 1200, 2), problem(5000, 900, 3)]
+    ms = [pkg.ORBmatcher(0.8, True) for _ in probs]
+
+    def solve(m, P, use_second):
+        F = pkg.FrameView(P["kps"], P["desc"], (0.0, 752.0, 0.0, 480.0))
+        n, moq, bd = m.search_window(F, P["qdesc"], P["u"], P["v"], P["radius"], P["minl"], P["maxl"], nnratio=0.75, th_dist=70, use_second=use_second)
+        return n, moq.tobytes(), bd.tobytes(), F.slot.tobytes()
+    try:
+        ref = [[solve(ms[0], P, us) for us in (True, False)] for P in probs]
+        assert all(r[0][0] > 100 for r in ref)
+        P = probs[0]
+        OF = oracle.OracleFrame(P["kps"]["x"], P["kps"]["y"], P["kps"]["octave"], P["kps"]["angle"], P["desc"], (0.0, 752.0, 0.0, 480.0), sf)
+        n_ref, moq_ref, bd_ref = OF.search_by_projection_win(P["qdesc"], P["u"], P["v"], P["radius"], P["minl"], P["maxl"], 0.75, 70, True)
+        assert (n_ref, moq_ref.tobytes(), bd_ref.tobytes()) == ref[0][0][:3]
+        bad = []
+
+        def worker(k):
+            def run():
+                for it in range(50):
+                    j = (k + it) % len(probs)            # every handle sees every problem size: buffers regrow under concurrency
+                    us = it % 2 == 0
+                    if solve(ms[k], probs[j], us) != ref[j][0 if us else 1]:
+                        bad.append((k, it, j, us))
+            return run
+        _run_threads([worker(k) for k in range(3)])
+        assert not bad, bad[:5]
+    finally:
+        for m in ms:
+            m.close()
+    del rng
+
+
+def test_extractor_and_matcher_threads_mixed(pkg, frame):
+    """Tracking extracts while LocalMapping / LoopClosing search: one extractor thread + two matcher threads on one device."""
+    img = frame(1003)
+    ex = pkg.ORBextractor(**EUROC)
+    m1, m2 = pkg.ORBmatcher(0.9, True), pkg.ORBmatcher(0.6, False)
+    try:
+        mono, k, d = ex(img, None, (0, 1000))
+        refx = (mono, k.tobytes(), d.tobytes())
+        F0 = pkg.FrameView(k, d, (0.0, 752.0, 0.0, 480.0))
+        nq = len(k)
+        args = (d, (k["x"] + np.float32(1.5)).astype(np.float32), (k["y"] - np.float32(0.5)).astype(np.float32), np.full(nq, 12.0, np.float32),
+                np.full(nq, -1, np.int32), np.full(nq, -1, np.int32))
+        n0, moq0, bd0 = m1.search_window(F0, *args, nnratio=0.9, th_dist=100, use_second=True)
+        assert n0 > 500
+        bad = []
+
+        def xrun():
+            for it in range(50):
+                mono, kk, dd = ex(img, None, (0, 1000))
+                if (mono, kk.tobytes(), dd.tobytes()) != refx:
+                    bad.append(("x", it))
+
+        def mrun(m):
+            def run():
+                for it in range(50):
+                    F = pkg.FrameView(k, d, (0.0, 752.0, 0.0, 480.0))
+                    n, moq, bd = m.search_window(F, *args, nnratio=0.9, th_dist=100, use_second=True)
+                    if n != n0 or not np.array_equal(moq, moq0) or not np.array_equal(bd, bd0):
+                        bad.append(("m", it))
+            return run
+        _run_threads([xrun, mrun(m1), mrun(m2)])
+        assert not bad, bad[:5]
+    finally:
+        ex.close(); m1.close(); m2.close()
