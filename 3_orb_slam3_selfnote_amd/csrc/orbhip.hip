@@ -80,7 +80,9 @@ struct orbx_handle {
   // last call
   FrameParams last{};
   bool have_last = false;
-  hipEvent_t last_done = nullptr;   // recorded on the extraction's stream behind its last kernel
+  hipEvent_t last_done = nullptr;   // recorded on the extraction's stream behind its last kernel (asynchronous entry point only)
+  bool last_pending = false;        // ... and not yet known to have completed
+  bool in_capture = false;          // orbx_extract is capturing its per-frame graph: nothing but the frame's own work is enqueued
   DevBuf stereo[7];  // grow-only buffers of orbx_compute_stereo_matches
   DevBuf maps[2];    // rectification maps of orbx_remap_linear, kept between calls
   int maps_rows = 0, maps_cols = 0;
@@ -101,6 +103,19 @@ struct orbx_handle {
   bool stage_valid = false;
   std::string err;
 };
+
+// Synchronous copies go through the handle's own non-blocking stream, never through the legacy default stream: another host
+// thread may be capturing its per-frame graph (orbx_extract), and a legacy-stream operation would implicitly join - and
+// invalidate - that capture ("operation would make the legacy stream depend on a capturing blocking stream").
+static hipError_t copy_on(hipStream_t s, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+// waits (on the handle's stream) for the last extraction of this handle, whatever stream it ran on
+static hipError_t join_last(orbx_handle *h) {
+  if (h->last_pending) { hipError_t e = hipStreamWaitEvent(h->stream, h->last_done, 0); if (e != hipSuccess) return e; }
+  return hipStreamSynchronize(h->stream);
+}
 
 #define XCHECK(h, call)                                                                       \
   do {                                                                                        \
@@ -213,7 +228,7 @@ orbx_t *orbx_create(int nfeatures, float scaleFactor_, int nlevels, int iniThFAS
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
   if (h->d_disc.reserve(disc.size()) != hipSuccess ||
-      hipMemcpy(h->d_disc.p, disc.data(), disc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      copy_on(h->stream, h->d_disc.p, disc.data(), disc.size(), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipStreamDestroy(h->stream);
     delete h;
     return nullptr;
@@ -436,13 +451,13 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_lcnt.reserve(sizeof(int32_t) * 2 * nl * B));
   XCHECK(h, h->d_candCnt.reserve(sizeof(int32_t) * nl * B));
   XCHECK(h, h->d_cells.reserve(sizeof(uint32_t) * cellrec.size()));
-  XCHECK(h, hipMemcpy(h->d_cells.p, cellrec.data(), sizeof(uint32_t) * cellrec.size(), hipMemcpyHostToDevice));
+  XCHECK(h, copy_on(h->stream, h->d_cells.p, cellrec.data(), sizeof(uint32_t) * cellrec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_tiles.reserve(sizeof(uint32_t) * tilerec.size()));
-  XCHECK(h, hipMemcpy(h->d_tiles.p, tilerec.data(), sizeof(uint32_t) * tilerec.size(), hipMemcpyHostToDevice));
+  XCHECK(h, copy_on(h->stream, h->d_tiles.p, tilerec.data(), sizeof(uint32_t) * tilerec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_xtab.reserve(sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
   XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
-  if (!xtab.empty()) XCHECK(h, hipMemcpy(h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
-  if (!ytab.empty()) XCHECK(h, hipMemcpy(h->d_ytab.p, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
+  if (!xtab.empty()) XCHECK(h, copy_on(h->stream, h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
+  if (!ytab.empty()) XCHECK(h, copy_on(h->stream, h->d_ytab.p, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
   // k_octree LDS: node arrays (72 B per node) + scan scratch, plus the level's cell offsets when they fit
   int maxCells = 1;
   for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, g[l].nCols * g[l].nRows);
@@ -565,8 +580,11 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   h->last = P;
   h->have_last = true;
   // consumers of this batch on OTHER streams (orbx_compute_stereo_matches, orbx_download_*) order themselves behind it
-  if (!h->last_done) XCHECK(h, hipEventCreateWithFlags(&h->last_done, hipEventDisableTiming));
-  XCHECK(h, hipEventRecord(h->last_done, s));
+  if (!h->in_capture) {
+    if (!h->last_done) XCHECK(h, hipEventCreateWithFlags(&h->last_done, hipEventDisableTiming));
+    XCHECK(h, hipEventRecord(h->last_done, s));
+    h->last_pending = true;
+  }
   return 0;
 }
 
@@ -621,7 +639,9 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
       if (h->graph) { (void)hipGraphExecDestroy(h->graph); h->graph = nullptr; }
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        h->in_capture = true;
         const int r = enqueue();
+        h->in_capture = false;
         const hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (r == 0 && e == hipSuccess && g && hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0) == hipSuccess) {
           K.rows = rows; K.cols = cols; K.lap0 = lap0; K.lap1 = lap1; K.icap = icap; K.pin_in = h->pin_in; K.pin_out = h->pin_out;
@@ -644,6 +664,7 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
   }
   if (!launched) { rc = enqueue(); if (rc < 0) return rc; }
   XCHECK(h, hipStreamSynchronize(h->stream));
+  h->last_pending = false;   // this entry point returns with the frame's work complete
   int32_t counts[2];
   memcpy(counts, po, sizeof(counts));
   *n_out = counts[0];
@@ -838,9 +859,9 @@ int orbx_level_info(const orbx_t *h, int level, int *rows, int *cols) {
 
 static int download_plane(orbx_t *h, const uint8_t *src, size_t spitch, int w, int hh, int border, uint8_t *dst, size_t dst_stride) {
   std::vector<uint8_t> tmp((size_t)w * hh);
+  XCHECK(h, join_last(h));
+  XCHECK(h, hipMemcpy2DAsync(tmp.data(), (size_t)w, src, spitch, (size_t)w, (size_t)hh, hipMemcpyDeviceToHost, h->stream));
   XCHECK(h, hipStreamSynchronize(h->stream));
-  XCHECK(h, hipDeviceSynchronize());
-  XCHECK(h, hipMemcpy2D(tmp.data(), (size_t)w, src, spitch, (size_t)w, (size_t)hh, hipMemcpyDeviceToHost));
   auto refl = [](int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
@@ -874,7 +895,7 @@ int orbx_download_blurred_level(orbx_t *h, int frame, int level, uint8_t *dst, s
 
 static int download_packed(orbx_t *h, const uint32_t *src, int n, float *xyr, int cap) {
   std::vector<uint32_t> tmp((size_t)std::max(n, 1));
-  if (n > 0) XCHECK(h, hipMemcpy(tmp.data(), src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  if (n > 0) XCHECK(h, copy_on(h->stream, tmp.data(), src, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
   for (int i = 0; i < n && i < cap; i++) {
     xyr[3 * i] = (float)(tmp[i] & 0xfff);
     xyr[3 * i + 1] = (float)((tmp[i] >> 12) & 0xfff);
@@ -886,18 +907,18 @@ static int download_packed(orbx_t *h, const uint32_t *src, int n, float *xyr, in
 int orbx_download_candidates(orbx_t *h, int frame, int level, float *xyr, int cap) {
   if (!h || !h->have_last || !xyr || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes) return ORBX_E_ARG;
   XCHECK(h, hipSetDevice(h->device));
-  XCHECK(h, hipDeviceSynchronize());
+  XCHECK(h, join_last(h));
   int32_t n = 0;
-  XCHECK(h, hipMemcpy(&n, h->last.candCnt + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
+  XCHECK(h, copy_on(h->stream, &n, h->last.candCnt + (size_t)frame * h->nlevels + level, sizeof(n), hipMemcpyDeviceToHost));
   return download_packed(h, h->last.cand + (size_t)frame * h->last.cand_fs + h->geom[level].candBase, n, xyr, cap);
 }
 
 int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, int cap) {
   if (!h || !h->have_last || !xyr || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last.nframes) return ORBX_E_ARG;
   XCHECK(h, hipSetDevice(h->device));
-  XCHECK(h, hipDeviceSynchronize());
+  XCHECK(h, join_last(h));
   int32_t n[2] = {0, 0};
-  XCHECK(h, hipMemcpy(n, h->last.lcnt + ((size_t)frame * h->nlevels + level) * 2, sizeof(n), hipMemcpyDeviceToHost));
+  XCHECK(h, copy_on(h->stream, n, h->last.lcnt + ((size_t)frame * h->nlevels + level) * 2, sizeof(n), hipMemcpyDeviceToHost));
   return download_packed(h, h->last.lkp + (size_t)frame * h->last.lkp_fs + h->geom[level].kpBase, n[0], xyr, cap);
 }
 
@@ -2034,8 +2055,8 @@ int orbx_compute_stereo_matches(orbx_t *hl, int frame_l, orbx_t *hr, int frame_r
   hipStream_t s = hl->stream;
   // the two extractions may have run on any stream (the handles' own, or the caller's with orbx_extract_batch_device): the
   // search is ordered behind the last kernel of both; level 0 is read in place from the caller's images (orbhip.h)
-  if (hl->last_done) XCHECK(hl, hipStreamWaitEvent(s, hl->last_done, 0));
-  if (hr->last_done) XCHECK(hl, hipStreamWaitEvent(s, hr->last_done, 0));
+  if (hl->last_pending) XCHECK(hl, hipStreamWaitEvent(s, hl->last_done, 0));
+  if (hr->last_pending) XCHECK(hl, hipStreamWaitEvent(s, hr->last_done, 0));
   DevBuf *bufs = hl->stereo;
   const size_t sz[7] = {sizeof(orbx_keypoint_t) * (size_t)nL, sizeof(orbx_keypoint_t) * (size_t)nR, 32 * (size_t)nL, 32 * (size_t)nR,
                         sizeof(float) * (size_t)nL, sizeof(float) * (size_t)nL, sizeof(int32_t) * (size_t)nL};

@@ -20,25 +20,40 @@ def chunk_for_rank(nframes, rank, world):
     return lo, hi
 
 
-def init_distributed(backend):
+def init_distributed(backend, device=None):
+    """One process per GPU; RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run, or bench.py's own launcher).
+    `device`: the rank's torch.device for backend "nccl" (= RCCL), which binds the communicator to it."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl" and device is not None:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
 
-def timed_steps(step, steps, warmup, sync=lambda: None, world=1, device=None):
+def finish_distributed():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def timed_steps(step, steps, warmup, sync=lambda: None, world=1, device=None, before_timed=None):
     """bench.py's timing contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on
-    both sides; returns the MAX elapsed seconds over ranks."""
+    both sides; returns the MAX elapsed seconds over ranks.  `before_timed` runs once between the warm-up and the first barrier
+    (bench.py switches its per-kernel event recording on there).  `device`: where the MAX all-reduce's tensor lives (the rank's
+    GPU for "nccl", None = host memory for "gloo")."""
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
         step()
     sync()
+    if before_timed is not None:
+        before_timed()
     if world > 1:
         dist.barrier()
     sync()

@@ -1,24 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s of ORB extract + match on 752x480 frames (BASELINE.json metric), MI355X.
+"""bench.py -- frames/s of ORB extract + match (BASELINE.json metric) on MI355X.
 
-Workload (config.workload = BASELINE.json configs[2]): synthetic frame stream, 752x480, 8 levels,
-1000 features, FAST 20/7, lapping {0,1000}; every frame is extracted (ORBextractor::operator()) and matched against
-its predecessor with the SearchByProjection core in the "1000x1000" stress setting (window = whole image, levels open,
-nnratio 0.8, TH_HIGH 100, sequential claims on).
+Workloads (`--config`):
+  euroc  BASELINE configs[2] (the configuration the metric is quoted on): synthetic 752x480 stream, 8 levels, 1000
+         features, FAST 20/7, lapping {0,1000}; every frame is extracted (ORBextractor::operator()) and matched against its predecessor
+         with the SearchByProjection core in the "1000x1000" stress setting (window = whole image, levels open, nnratio 0.8,
+         TH_HIGH 100, sequential claims on).
+  tumvi  BASELINE configs[4]: 512x512, 1500 features, last-frame SearchByProjection (ORBmatcher.cc:2027-2289) whose windows come
+         from KannalaBrandt8::project with the TUM_512.yaml:9-19 parameters, th 15; map points resident in HBM.
 
-A step = one pass of the hot path over one batch of B frames that are already resident in HBM.  One process per GPU;
-frames shard across ranks with no data-path collective, so scaling is weak: every rank runs B frames
-per step and `value` = (world * B * steps) / max-over-ranks(time).
+A batch = B frames that are already resident in HBM: 12 extraction launches + the search launches on one stream.  A STEP =
+`--batches-per-step` batches (default 32 x 256 = 8192 frames per GPU), dealt round-robin to `--streams` independent pipelines, so
+that the driver's 20-step run keeps the GPU busy for about a second.  The batches of a step cycle through `--groups` different
+frame sets (2048 distinct frames per GPU by default).
+
+One process per GPU; frames shard across ranks with no data-path collective, so scaling is weak: every rank runs
+the same number of frames per step and `value` = world * frames per step * steps / max-over-ranks(time).
+`python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (fresh child processes, created before this process
+touches the GPU runtime); under torch.distributed.run the ranks come from the environment.
 
 Extra keys on the JSON line:
-  roofline      dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the launch
-                stream, measured here, see also profiles/), against the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (oracle/, kind "port") timed on this host, one core, bounded sample (rank 0, N=1 only)
+  roofline         dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the launch stream,
+                   measured over the timed region; see also profiles/), against the 8 TB/s HBM peak; `valu_issue`: the step's vector
+                   instructions per second against the MEASURED issue ceiling of its opcode mix (profiles/valu_calib.json)
+  verified_frames  frames of the LAST TIMED STEP whose keypoints, descriptors and match indices are byte-equal to the CPU oracle's
+                   (non-zero exit status on any mismatch)
+  cpu_baseline     the CPU oracle (oracle/, kind "port") timed natively on this host per BASELINE.md section 3: one core and all
+                   cores (one frame per thread), median and mean, extract / match split (rank 0, N=1 only)
+  host_fed         the same pipeline fed from pinned host memory (H2D double-buffered on a copy stream, D2H of counts, keypoints,
+                   descriptors and match indices): frames/s and PCIe GB/s.  `value` stays the HBM-resident rate.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,109 +44,185 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W = 480, 752
-CFG = dict(nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PCIE_SPEC_GBS = 63.0    # same table: PCIe Gen5 x16
 LAP = (0, 1000)
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+CONFIGS = {
+    "euroc": dict(H=480, W=752, cfg=dict(nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),
+                  workload="BASELINE configs[2]: extract + SearchByProjection match, 1000x1000 candidates, synthetic frame stream",
+                  metric="frames/sec ORB extract+match, 752x480"),
+    "tumvi": dict(H=512, W=512, cfg=dict(nfeatures=1500, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),
+                  workload="BASELINE configs[4]: TUM-VI 512x512, 1500 features, KannalaBrandt8 projection in the last-frame SearchByProjection",
+                  metric="frames/sec ORB extract+match, 512x512 KannalaBrandt8"),
+}
+TUMVI_TH = 15.0         # Tracking.cc:2898: th = 15 for monocular frames
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc")
+    ap.add_argument("--batch", type=int, default=256, help="frames per batch (one launch sequence)")
+    ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step: a step is batch * batches_per_step frames per GPU")
+    ap.add_argument("--groups", type=int, default=8, help="distinct frame sets of `batch` frames resident in HBM")
+    ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (batches alternate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (also skips verified_frames)")
+    ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1])")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a launcher: N fresh child processes, one per GPU, created before this process makes any GPU call (it
+    never does).  Rank 0 inherits stdout (the JSON line); the exit status is the worst of the ranks'."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return max((abs(rc) for rc in rcs), default=0)
 
 
 def algorithmic_bytes(level_shapes, n_kp):
     """each stage reads its inputs once and writes its outputs once (bytes per frame)."""
     px = [h * w for (h, w) in level_shapes]
     P, P0, P7 = sum(px), px[0], px[-1]
-    stages = {
-        "pyramid": (P - P7) + (P - P0),
-        "fast": P,
-        "blur": 2 * P,
-        "describe": 749 * n_kp + 512 * n_kp + 32 * n_kp + 28 * n_kp,
-        "octree": 0,  # filled by the caller from the measured candidate count
-    }
-    return stages
+    return {"pyramid": (P - P7) + (P - P0), "fast": P, "blur": 2 * P, "describe": 749 * n_kp + 512 * n_kp + 32 * n_kp + 28 * n_kp, "octree": 0}
 
 
-def cpu_baseline(frames, offs, budget_s=12.0):
-    """Time the CPU oracle (clean-room port of the reference's algorithm) on a bounded sample, one core."""
+def stats_ms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 3), "mean": round(float(a.mean()), 3)}
+
+
+def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads):
+    """BASELINE.md section 3 over the oracle (native driver, oracle/orb_cpu_bench.c) + the parity tie of the timed region:
+    one core over the frame set the GPU's last timed batch worked on (every frame compared), all cores over every resident set."""
     from oracle import oracle_py as O
-    ex = O.OracleExtractor(**CFG)
-    sf = ex.scale_factors
-    prev = None
-    t0 = time.perf_counter()
-    n = 0
-    for t in list(range(len(frames))) * 4:                              # cycle the stream until the time budget is used
-        mono, kps, desc = ex.extract(frames[t], LAP)
-        if prev is not None and len(kps):
-            pk, pd, po = prev
-            F = O.OracleFrame(kps["x"], kps["y"], kps["octave"], kps["angle"], desc, (0.0, float(W), 0.0, float(H)), sf)
-            u = (pk["x"] + np.float32(po[0] - offs[t][0])).astype(np.float32)  # (wrap-around pair at t == 0: large shift, still a valid query set)
-            v = (pk["y"] + np.float32(po[1] - offs[t][1])).astype(np.float32)
-            m1 = np.full(len(pk), -1, np.int32)
-            F.search_by_projection_win(pd, u, v, np.full(len(pk), 1.0e4, np.float32), m1, m1, 0.8, 100, True)
-        prev = (kps, desc, offs[t])
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same synthetic stream, extract + 1000x1000 match, oracle/liborb_oracle.so (gcc -O2), %.1f s" % (n, dt)}
+    ex = O.OracleExtractor(**conf["cfg"])
+    mode = 1 if conf is CONFIGS["tumvi"] else 0
+
+    def scene_of(g):
+        if mode == 0:
+            return None
+        s = scene_host[g]
+        return dict(cam_type=1, cam=s["cam"], Xw=s["Xw"], has_mp=s["has"], Tcw=s["Tcw"], Tlw=s["Tlw"], th=TUMVI_TH, check_ori=1,
+                    bounds=(0.0, float(conf["W"]), 0.0, float(conf["H"])))
+
+    frames, offs = groups[g_last]
+    B = len(frames)
+    r1 = O.bench_stream(ex, frames, offs, B, threads=1, warmup=50, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100, scene=scene_of(g_last))
+    # ---- parity tie: the last timed batch of the GPU against the oracle, frame by frame
+    bad = []
+    verified = 0
+    for t in range(B):
+        n = int(r1["counts"][t, 0])
+        ok = n == int(gpu_last["cnt"][t, 0]) and int(r1["counts"][t, 1]) == int(gpu_last["cnt"][t, 1])
+        ok = ok and r1["kps"][t, :n].tobytes() == gpu_last["kps"][t, :n].tobytes() and np.array_equal(r1["desc"][t, :n], gpu_last["desc"][t, :n])
+        if ok and "match" in gpu_last:
+            nl = int(r1["counts"][(t - 1) % B, 0])
+            m = nl if mode == 0 else n           # mode 0: match_of_query of the last frame's keypoints; mode 1: slot array of the current frame
+            ok = int(r1["nmatch"][t]) == int(gpu_last["nm"][t]) and np.array_equal(r1["moq"][t, :m], gpu_last["match"][t, :m])
+        if ok:
+            verified += 1
+        else:
+            bad.append(t)
+    tot1 = r1["ms_extract"] + r1["ms_match"]
+    one = {"frames": B, "warmup_frames": 50, "extract_ms": stats_ms(r1["ms_extract"]), "match_ms": stats_ms(r1["ms_match"]), "total_ms": stats_ms(tot1),
+           "fps": round(B / (r1["wall_extract"] + r1["wall_match"]), 3), "extract_fps": round(B / r1["wall_extract"], 3)}
+    # ---- all cores, one frame per thread, every resident frame set (>= 2000 frames)
+    nfr, we, wm = 0, 0.0, 0.0
+    for g in range(len(groups)):
+        fr, of = groups[g]
+        ra = O.bench_stream(ex, fr, of, len(fr), threads=nthreads, warmup=nthreads if g == 0 else 0, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100,
+                            scene=scene_of(g))
+        nfr += len(fr); we += ra["wall_extract"]; wm += ra["wall_match"]
+    allc = {"threads": nthreads, "frames": nfr, "fps": round(nfr / (we + wm), 3), "extract_fps": round(nfr / we, 3), "match_fps": round(nfr / wm, 3)}
+    out = {"value": one["fps"], "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "oracle/liborb_oracle.so (gcc -O3 -ffp-contract=off), native timer around each call (orb_cpu_bench.c), same synthetic stream: "
+                     "1 core: %d frames after 50 warm-up frames; %d threads, one frame per thread: %d frames" % (B, nthreads, nfr),
+           "one_core": one, "all_cores": allc}
+    return out, verified, bad
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80)   # 80 x 256 frames: the drain of the 4-deep pipeline at the end is ~3 % of the region
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
-    ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (steps alternate)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1])")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))           # parent: no torch, no HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one process per GPU; backend "nccl" (= RCCL) for the barrier / MAX-time all-reduce.  ORB_BENCH_BACKEND=gloo lets several
-    # ranks rehearse the N>1 path on a box with fewer GPUs (ranks then share devices modulo the device count).
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or leave WORLD_SIZE unset\n"
+                         % (args.gpus, world, args.gpus))
+        sys.exit(2)
+    conf = CONFIGS[args.config]
+    H, W, CFG = conf["H"], conf["W"], conf["cfg"]
+    B, S, G, NB = args.batch, max(1, args.streams), max(1, args.groups), max(1, args.batches_per_step)
     backend = os.environ.get("ORB_BENCH_BACKEND", "nccl")
+    selftest = os.environ.get("ORB_BENCH_SELFTEST") == "1"   # plumbing test without a device (tests/test_bench_launch.py): no hot path runs
     if world > 1:   # before anything initialises the GPU runtime: the host driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    shard = importlib.import_module("3_orb_slam3_selfnote_amd.shard")
+    frames_per_step = B * NB
+
+    if selftest:
+        shard.init_distributed(backend if backend != "nccl" else "gloo")
+        dt = shard.timed_steps(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, world=world)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "metric": conf["metric"], "value": round(shard.aggregate_fps(frames_per_step, args.steps, world, dt), 2),
+                              "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                              "scaling": "weak", "data": "none (ORB_BENCH_SELFTEST: no device work, launcher / barrier / MAX plumbing only)"}))
+        shard.finish_distributed()
+        return
+
     ndev = max(torch.cuda.device_count(), 1)
-    dev_index = local_rank % ndev
+    dev_index = local_rank % ndev           # ORB_BENCH_BACKEND=gloo lets several ranks rehearse the N>1 path on fewer GPUs
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", dev_index)
-    local_rank = dev_index
+    shard.init_distributed(backend, device=dev if backend == "nccl" else None)
     pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
-
-    B = args.batch
-    frames, offs = synth.make_stream(1000 + rank, B, H, W)          # B distinct frames of one moving scene
-    d_img = torch.from_numpy(frames).to(dev)                         # inputs resident in HBM before timing starts
-    # shift of the scene between frame t-1 and t (pair p: queries = slot p, candidates = slot p+1)
-    shift = np.zeros((B, 2), dtype=np.float32)
-    for p in range(B):
-        prev = offs[p - 1] if p > 0 else offs[B - 1]
-        shift[p] = (prev[0] - offs[p][0], prev[1] - offs[p][1])
-    d_shift = torch.from_numpy(shift).to(dev)
     C = pkg.C
+    tumvi = args.config == "tumvi"
+
+    # ---- resident inputs: G frame sets of B frames each (distinct crops of G moving synthetic scenes, SURVEY.md 8d)
+    groups = [synth.make_stream(1000 + 64 * rank + g, B, H, W) for g in range(G)]
+    d_img = [torch.from_numpy(f).to(dev) for f, _ in groups]
+    d_shift = []
+    for f, offs in groups:   # pair p: queries = frame p-1 (wrapping to B-1), candidates = frame p
+        sh = np.array([(offs[p - 1][0] - offs[p][0], offs[p - 1][1] - offs[p][1]) for p in range(B)], dtype=np.float32)
+        d_shift.append(torch.from_numpy(sh).to(dev))
 
     class Pipe:
-        """One independent extract+match pipeline: its own handles, workspace, outputs and HIP stream.  Consecutive steps
-        alternate between args.streams pipelines so that the latency-bound kernels of one step (octree, in-order match
-        resolve) overlap the throughput-bound kernels of the next (separate HIP streams, no dependency between steps)."""
+        """One independent extract+match pipeline: its own handles, workspace, outputs and HIP stream.  Consecutive batches alternate
+        between the pipelines so that the latency-bound kernels of one batch (octree, in-order match resolve) overlap the
+        throughput-bound kernels of the next (separate HIP streams, no dependency between batches)."""
 
         def __init__(self):
-            self.ex = pkg.ORBextractor(device=local_rank, **CFG)
-            self.mt = pkg.ORBmatcher(0.8, True, device=local_rank)
+            self.ex = pkg.ORBextractor(device=dev_index, **CFG)
+            self.mt = pkg.ORBmatcher(0.8 if not tumvi else 0.9, True, device=dev_index)
             self.cap = cap = self.ex.configure(H, W, B)
             self.stream = torch.cuda.Stream(device=dev)
-            # slot 0 = last frame of the previous step (query side of pair 0); slots 1..B = this step's frames
+            # slot 0 = the last frame of the set (query side of pair 0); slots 1..B = the set's frames
             self.d_kps = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
             self.d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
             self.d_cnt = torch.zeros((B + 1, 2), dtype=torch.int32, device=dev)
@@ -139,85 +232,128 @@ def main():
             self.d_sobs = torch.empty((B, cap), dtype=torch.uint8, device=dev)
             self.d_moq = torch.empty((B, cap), dtype=torch.int32, device=dev)
             self.d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.kp1 = self.d_kps[1:]
-            self.fs = pkg.FrameStruct(cap, self.kp1.data_ptr(), self.d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
+            self.fs = pkg.FrameStruct(cap, self.d_kps[1:].data_ptr(), self.d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
+            self.group = -1
 
-        def step(self):
+        def batch(self, g, images=None, scene=None):
             cap, ex, mt = self.cap, self.ex, self.mt
             d_kps, d_desc, d_cnt = self.d_kps, self.d_desc, self.d_cnt
+            self.group = g
             with torch.cuda.stream(self.stream):
                 stream = self.stream.cuda_stream
-                # carry the last frame of the previous pass into slot 0 (60 KB device copy)
-                d_kps[0].copy_(d_kps[B]); d_desc[0].copy_(d_desc[B]); d_cnt[0].copy_(d_cnt[B])
-                ex.extract_batch_device(d_img.data_ptr(), H, W, W, H * W, B, self.kp1.data_ptr(), d_desc[1:].data_ptr(), d_cnt[1:].data_ptr(), cap, LAP, stream=stream)
+                img = d_img[g] if images is None else images
+                ex.extract_batch_device(img.data_ptr(), H, W, W, H * W, B, d_kps[1:].data_ptr(), d_desc[1:].data_ptr(), d_cnt[1:].data_ptr(), cap, LAP, stream=stream)
                 if args.no_match:
                     return
-                # caller-side projection of the previous frame's features into the current frame (pure shift in this stream)
-                u = (d_kps[:B, :, 0] + d_shift[:, 0:1]).contiguous()
-                v = (d_kps[:B, :, 1] + d_shift[:, 1:2]).contiguous()
+                # the set's last frame is the predecessor of its first (60 KB device copy)
+                d_kps[0].copy_(d_kps[B]); d_desc[0].copy_(d_desc[B]); d_cnt[0].copy_(d_cnt[B])
                 self.d_slot.fill_(-1); self.d_sobs.zero_()                  # Frame ctor: mvpMapPoints = NULL
-                qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), self.d_radius.data_ptr(), self.d_lvl.data_ptr(), self.d_lvl.data_ptr(), None, None)
-                rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(self.fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
-                                                                 C.c_void_p(d_cnt.data_ptr()), 2, B, C.c_float(0.8), 100, 1,
-                                                                 C.c_void_p(self.d_slot.data_ptr()), C.c_void_p(self.d_sobs.data_ptr()), C.c_void_p(self.d_moq.data_ptr()),
-                                                                 None, C.c_void_p(self.d_nm.data_ptr()), C.c_void_p(stream))
+                if not tumvi:
+                    # caller-side projection of the previous frame's features into the current frame (pure shift in this stream)
+                    u = (d_kps[:B, :, 0] + d_shift[g][:, 0:1]).contiguous()
+                    v = (d_kps[:B, :, 1] + d_shift[g][:, 1:2]).contiguous()
+                    qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), self.d_radius.data_ptr(), self.d_lvl.data_ptr(), self.d_lvl.data_ptr(), None, None)
+                    rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(self.fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
+                                                                     C.c_void_p(d_cnt.data_ptr()), 2, B, C.c_float(0.8), 100, 1,
+                                                                     C.c_void_p(self.d_slot.data_ptr()), C.c_void_p(self.d_sobs.data_ptr()), C.c_void_p(self.d_moq.data_ptr()),
+                                                                     None, C.c_void_p(self.d_nm.data_ptr()), C.c_void_p(stream))
+                else:
+                    sc = scene[g]     # the map: world points, poses (resident in HBM); descriptors / octaves / angles = the last frame's own
+                    last = pkg.LastFrameStruct(cap, sc["has"].data_ptr(), sc["Xw"].data_ptr(), d_desc.data_ptr(), d_kps.data_ptr(), None,
+                                               sc["Tcw"].data_ptr(), sc["Tlw"].data_ptr())
+                    rc = mt.L.orbm_search_by_projection_last_frame_batch_device(
+                        mt.m, C.byref(self.fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(last), cap, C.c_void_p(d_cnt.data_ptr()), 2, B,
+                        sf_host.ctypes.data_as(C.c_void_p), len(sf_host), 1, kb8.ctypes.data_as(C.c_void_p), C.c_float(0.0), C.c_float(0.0), C.c_float(TUMVI_TH), 1, 1,
+                        C.c_void_p(self.d_slot.data_ptr()), C.c_void_p(self.d_sobs.data_ptr()), C.c_void_p(self.d_moq.data_ptr()), C.c_void_p(self.d_nm.data_ptr()),
+                        C.c_void_p(stream))
                 if rc < 0:
-                    raise RuntimeError("orbm_search_by_projection_batch_device rc=%d %s" % (rc, mt.L.orbm_last_error(mt.m)))
+                    raise RuntimeError("search rc=%d %s" % (rc, mt.L.orbm_last_error(mt.m)))
 
-    pipes = [Pipe() for _ in range(max(1, args.streams))]
+    pipes = [Pipe() for _ in range(S)]
     cap = pipes[0].cap
     level_shapes = [pipes[0].ex.level_shape(l) for l in range(CFG["nlevels"])]
-    # set-up: every pipeline runs once so that its lazily sized device buffers and kernel attributes exist before any step is
-    # counted, whatever --warmup is (the W warm-up steps below alternate between the pipelines like the timed ones)
-    for pp in pipes:
-        pp.step()
+    sf_host = np.ascontiguousarray(pipes[0].ex.GetScaleFactors(), dtype=np.float32)
+    kb8 = np.ascontiguousarray(synth.TUMVI_KB8)
+
+    # ---- tumvi: the map.  One untimed extraction per frame set gives the keypoints; the map points of pair p are those keypoints
+    # (frame p-1) un-projected through the KannalaBrandt8 model at their position in frame p (synth.make_last_frame_scene).
+    scene_dev, scene_host = None, None
+    if tumvi and not args.no_match:
+        scene_dev, scene_host = [], []
+        pp = pipes[0]
+        for g in range(G):
+            saved, args.no_match = args.no_match, True
+            pp.batch(g)
+            args.no_match = saved
+            torch.cuda.synchronize()
+            cnt = pp.d_cnt[1:].cpu().numpy()
+            kk = pp.d_kps[1:].cpu().numpy()
+            offs = groups[g][1]
+            Xw = np.zeros((B, cap, 3), np.float32); Tcw = np.zeros((B, 16), np.float32); Tlw = np.zeros((B, 16), np.float32)
+            has = np.zeros((B, cap), np.uint8)
+            for p in range(B):
+                l = (p - 1) % B
+                n = int(cnt[l, 0])
+                x, T, Tl = synth.make_last_frame_scene(1, kb8, kk[l, :n, 0], kk[l, :n, 1], (offs[l][0] - offs[p][0], offs[l][1] - offs[p][1]), 7000 + 977 * g + p)
+                Xw[p, :n] = x; Tcw[p] = T.reshape(-1); Tlw[p] = Tl.reshape(-1); has[p, :n] = 1
+            scene_host.append(dict(cam=kb8, Xw=Xw, Tcw=Tcw, Tlw=Tlw, has=has))
+            scene_dev.append({k: torch.from_numpy(v).to(dev) for k, v in (("Xw", Xw), ("Tcw", Tcw), ("Tlw", Tlw), ("has", has))})
+
+    # set-up: every pipeline runs once so that its lazily sized device buffers exist before any step is counted
+    for k, pp in enumerate(pipes):
+        pp.batch(k % G, scene=scene_dev)
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
-        pipes[counter[0] % len(pipes)].step()
-        counter[0] += 1
+        for _ in range(NB):
+            j = counter[0]
+            pipes[j % S].batch((j // S) % G, scene=scene_dev)
+            counter[0] += 1
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # HIP events inside liborbhip, on each pipeline's own launch stream, around every kernel of every timed step (a ring of
-    # event sets per handle): the per-kernel averages below are measured over the timed region itself.
-    for pp in pipes:
-        pp.ex.set_profiling(True)
-        pp.mt.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def start_profiling():
+        # HIP events inside liborbhip, on each pipeline's own launch stream, around every kernel of the batches of the timed region (a
+        # ring of the 32 most recent event sets per handle)
+        for pp in pipes:
+            pp.ex.set_profiling(True)
+            pp.mt.set_profiling(True)
+
+    dt = shard.timed_steps(step, args.steps, args.warmup, sync=torch.cuda.synchronize, world=world,
+                           device=dev if backend == "nccl" else None, before_timed=start_profiling)
+    fps = shard.aggregate_fps(frames_per_step, args.steps, world, dt)
 
     acc, nsamp = {}, 0
     for pp in pipes:
         st = pp.ex.stage_ms()
         if not st:
-            continue                      # a pipeline that got no step (steps < streams)
+            continue
         if not args.no_match:
             st.update(pp.mt.stage_ms())
         for k, v in st.items():
             acc[k] = acc.get(k, 0.0) + v
         nsamp += 1
     acc = {k: v / nsamp for k, v in acc.items()}
-    # the same kernels alone on the chip (one pipeline, synchronised between steps): isolates kernel quality from sharing
+    # the last timed batch: what the parity tie compares
+    j_last = counter[0] - 1
+    p_last, g_last = pipes[j_last % S], (j_last // S) % G
+    gpu_last = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        gpu_last = {"cnt": p_last.d_cnt[1:].cpu().numpy(), "kps": p_last.d_kps[1:].cpu().numpy().view(np.uint8).reshape(B, cap, 28),
+                    "desc": p_last.d_desc[1:].cpu().numpy()}
+        from oracle import oracle_py as O
+        gpu_last["kps"] = gpu_last["kps"].reshape(B, cap * 28).view(O.KP_DTYPE).reshape(B, cap)
+        if not args.no_match:
+            gpu_last["nm"] = p_last.d_nm.cpu().numpy()
+            gpu_last["match"] = (p_last.d_slot if tumvi else p_last.d_moq).cpu().numpy()
+    cnt = p_last.d_cnt[1:].cpu().numpy()
+    n_kp = float(cnt[:, 0].mean())
+    nm_mean = float(p_last.d_nm.cpu().numpy().mean()) if not args.no_match else 0.0
+
+    # the same kernels alone on the chip (one pipeline, synchronised between batches): isolates kernel quality from sharing
     pipes[0].ex.set_profiling(True)       # resets the event ring
     pipes[0].mt.set_profiling(True)
     for _ in range(4):
-        pipes[0].step()
+        pipes[0].batch(0, scene=scene_dev)
         torch.cuda.synchronize()
     iso = pipes[0].ex.stage_ms()
     if not args.no_match:
@@ -225,11 +361,56 @@ def main():
     for pp in pipes:
         pp.ex.set_profiling(False)
         pp.mt.set_profiling(False)
-    d_cnt, d_nm = pipes[0].d_cnt, pipes[0].d_nm
 
-    cnt = d_cnt[1:].cpu().numpy()
-    n_kp = float(cnt[:, 0].mean())
-    nm = d_nm.cpu().numpy()
+    # ---- host-fed: frames in pinned host memory, H2D on copy streams double-buffered against compute, results back to pinned memory
+    host_fed = None
+    if rank == 0 and world == 1 and not args.no_host_fed:
+        h_img = torch.from_numpy(groups[0][0]).pin_memory()
+        nd = min(2, S)
+        stage = [torch.empty_like(d_img[0]) for _ in range(nd)]
+        cstream = [torch.cuda.Stream(device=dev) for _ in range(nd)]
+        h_out = [dict(cnt=torch.empty((B, 2), dtype=torch.int32).pin_memory(), kps=torch.empty((B, cap, 7), dtype=torch.float32).pin_memory(),
+                      desc=torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory(), moq=torch.empty((B, cap), dtype=torch.int32).pin_memory(),
+                      nm=torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(nd)]
+        done = [None] * nd
+
+        def fed_batch(k):
+            i = k % nd
+            pp = pipes[i]
+            with torch.cuda.stream(cstream[i]):
+                if done[i] is not None:
+                    cstream[i].wait_event(done[i])          # the batch that read this staging buffer (and wrote these outputs) has finished
+                stage[i].copy_(h_img, non_blocking=True)
+                up = cstream[i].record_event()
+            pp.stream.wait_event(up)
+            pp.batch(0, images=stage[i], scene=scene_dev)
+            with torch.cuda.stream(pp.stream):
+                h_out[i]["cnt"].copy_(pp.d_cnt[1:], non_blocking=True)
+                h_out[i]["kps"].copy_(pp.d_kps[1:], non_blocking=True)
+                h_out[i]["desc"].copy_(pp.d_desc[1:], non_blocking=True)
+                if not args.no_match:
+                    h_out[i]["moq"].copy_(pp.d_slot if tumvi else pp.d_moq, non_blocking=True)
+                    h_out[i]["nm"].copy_(pp.d_nm, non_blocking=True)
+                done[i] = pp.stream.record_event()
+
+        for k in range(4):
+            fed_batch(k)
+        torch.cuda.synchronize()
+        nfed = 24
+        t0 = time.perf_counter()
+        for k in range(nfed):
+            fed_batch(k)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - t0
+        up_b = H * W
+        down_b = 8 + cap * (28 + 32) + (0 if args.no_match else cap * 4 + 4)
+        ffps = nfed * B / tf
+        same = bool(torch.equal(h_out[0]["cnt"], pipes[0].d_cnt[1:].cpu()))
+        host_fed = {"value": round(ffps, 2), "unit": "frames/s", "batches": nfed, "buffers_in_flight": nd,
+                    "pcie_bytes_per_frame": {"h2d": up_b, "d2h": down_b}, "pcie_GBps": round(ffps * (up_b + down_b) / 1e9, 2),
+                    "h2d_GBps": round(ffps * up_b / 1e9, 2), "pcie_spec_GBps": PCIE_SPEC_GBS, "outputs_equal_resident_run": same,
+                    "note": "pinned host frames -> HBM on a copy stream, double-buffered against compute; counts, keypoints, descriptors, match indices back to pinned memory"}
+
     # ---- roofline of the dominant KERNEL (per launch).  Stage -> kernel: "pyramid" is nlevels-1 launches of k_resize.
     stage_bytes = algorithmic_bytes(level_shapes, n_kp)
     stage_bytes["match_scan"] = (n_kp + n_kp) * 32 + n_kp * 12        # SURVEY.md 8d, match: descriptors in, indices out
@@ -241,67 +422,83 @@ def main():
     kname, nl = kernels[dom]
     launch_bytes = stage_bytes.get(dom, 0) * B / nl
     ach = launch_bytes / (per_launch[dom] * 1e-3) / 1e9
-    fps = world * B * args.steps / dt
     total_bytes = sum(stage_bytes[k] for k in ("pyramid", "fast", "blur", "describe")) + (0 if args.no_match else stage_bytes["match_scan"])
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")              # measured separately with rocprofv3 --pmc (tools/collect_traffic.py)
-    if os.path.exists(tf) and B == 256:
+    tf_ = os.path.join(ROOT, "profiles", "traffic.json")              # measured separately with rocprofv3 --pmc (tools/collect_traffic.py)
+    if os.path.exists(tf_) and B == 256 and not tumvi:
         try:
-            tj = json.load(open(tf))
+            tj = json.load(open(tf_))
             hit = [v for k, v in tj.items() if k.startswith(kname)]
             if hit:
                 traffic = round(hit[0]["hbm_B"])
         except Exception:
             traffic = None
 
-    # VALU issue roofline of the whole step: wave-instructions per launch from the committed SQ_INSTS_VALU profile (a separate
-    # rocprofv3 --pmc run of this same workload, tools/collect_sq.py), time measured here.  A wave64 instruction occupies its
-    # SIMD for 4 cycles; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock issue at most 614.4 G wave-instructions/s.
+    # VALU issue roofline of the whole batch: wave-instructions per launch from the committed SQ_INSTS_VALU profile (a separate
+    # rocprofv3 --pmc run of this workload, tools/collect_sq.py); the ceiling is MEASURED per opcode class by csrc/orb_calib.h
+    # (profiles/valu_calib.json) and weighted with every kernel's own opcode mix (tools/valu_mix.py -> profiles/valu_mix.json).
     valu = None
-    sf = os.path.join(ROOT, "profiles", "sq_counters.json")
-    if os.path.exists(sf) and B == 256 and not args.no_match:
+    sfp, mixp = os.path.join(ROOT, "profiles", "sq_counters.json"), os.path.join(ROOT, "profiles", "valu_mix.json")
+    if os.path.exists(sfp) and os.path.exists(mixp) and B == 256 and not args.no_match and not tumvi:
         try:
-            sj = json.load(open(sf))
-            tot = 0.0
+            sj, mj = json.load(open(sfp)), json.load(open(mixp))
+            tot, tot_t = 0.0, 0.0
             for stage, (kn, launches) in kernels.items():
                 hit = [v for k, v in sj.items() if kn in k and "SQ_INSTS_VALU" in v]
-                tot += max(h["SQ_INSTS_VALU"] for h in hit) * launches if hit else 0.0
-            peak = 256 * 4 * 2.4e9 / 4
-            ach_i = tot / (dt / args.steps)
+                n_i = max(h["SQ_INSTS_VALU"] for h in hit) * launches if hit else 0.0
+                ceil = mj["kernels"].get(kn, {}).get("ceiling_G_wave_instr_per_s")
+                if n_i and ceil:
+                    tot += n_i
+                    tot_t += n_i / (ceil * 1e9)
+            peak = tot / tot_t
+            ach_i = tot / (dt / (args.steps * NB))
             valu = {"bound": "valu-issue", "achieved": round(ach_i / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
-                    "frac": round(ach_i / peak, 4), "wave_instructions_per_step": round(tot),
-                    "source": "profiles/sq_counters.json (SQ_INSTS_VALU per launch, separate --pmc run); time measured live"}
+                    "frac": round(ach_i / peak, 4), "wave_instructions_per_batch": round(tot),
+                    "source": "instructions: profiles/sq_counters.json (SQ_INSTS_VALU per launch, separate --pmc run); ceiling: measured per opcode class "
+                              "(profiles/valu_calib.json), weighted by each kernel's static opcode mix (profiles/valu_mix.json); time measured live"}
         except Exception:
             valu = None
 
+    rc = 0
     if rank == 0:
         out = {
-            "metric": "frames/sec ORB extract+match, 752x480" if not args.no_match else "frames/sec ORB extract, 752x480",
+            "metric": conf["metric"] if not args.no_match else conf["metric"].replace("extract+match", "extract"),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: extract + SearchByProjection match, 1000x1000 candidates, synthetic frame stream",
-                       "image": "%dx%d" % (W, H), "nfeatures": 1000, "nlevels": 8, "frames_per_step_per_gpu": B, "streams": len(pipes),
-                       "mean_keypoints_per_frame": round(n_kp, 1), "mean_matches_per_frame": round(float(nm.mean()), 1),
+            "config": {"workload": conf["workload"], "image": "%dx%d" % (W, H), "nfeatures": CFG["nfeatures"], "nlevels": CFG["nlevels"],
+                       "frames_per_step_per_gpu": frames_per_step, "batch": B, "batches_per_step": NB, "distinct_frames_per_gpu": G * B, "streams": S,
+                       "mean_keypoints_per_frame": round(n_kp, 1), "mean_matches_per_frame": round(nm_mean, 1),
                        "sharding": "frames round-robin, one process per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(launch_bytes), "avg_launch_ms": round(per_launch[dom], 4),
-                         "stage_ms_per_step": {k: round(v, 4) for k, v in acc.items()},
+                         "stage_ms_per_batch": {k: round(v, 4) for k, v in acc.items()},
                          "isolated": {"note": "same kernel with nothing else on the chip (1 stream)",
                                       "avg_launch_ms": round(iso[dom] / nl, 4),
                                       "achieved": round(launch_bytes / (iso[dom] / nl * 1e-3) / 1e9, 2),
                                       "frac": round(launch_bytes / (iso[dom] / nl * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                      "stage_ms_per_step": {k: round(v, 4) for k, v in iso.items()}},
+                                      "stage_ms_per_batch": {k: round(v, 4) for k, v in iso.items()}},
                          "pipeline_algorithmic_GBps": round(fps / world * total_bytes / 1e9, 2)},
         }
         if valu is not None and world == 1:
             out["roofline"]["valu_issue"] = valu
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, offs)
+        if host_fed is not None:
+            out["host_fed"] = host_fed
+        if gpu_last is not None:
+            nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads)
+            out["cpu_baseline"] = cb
+            out["verified_frames"] = verified
+            out["verified_of"] = B
+            if bad:
+                out["verify_mismatch_frames"] = bad[:16]
+                rc = 3
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        if rc:
+            sys.stderr.write("bench.py: the GPU's last timed batch differs from the CPU oracle on %d frames\n" % len(bad))
+    shard.finish_distributed()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

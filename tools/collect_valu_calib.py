@@ -24,16 +24,19 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "valu_calib.json"))
     ap.add_argument("--trips", type=int, default=2000)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--ops", default="", help="comma-separated opcode-class indices (default: all)")
+    ap.add_argument("--waves", default="1,2,4,8", help="resident wavefronts per SIMD to sweep")
     args = ap.parse_args()
     pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
     L = pkg.load()
     nops = L.orbx_calibration_valu_ops()
     out = {"unit": "G wave-instructions/s (whole chip)", "trips": args.trips, "instructions_per_trip": 128,
            "note": "independent instruction streams, 16 chains per lane; residency fixed by LDS; see csrc/orb_calib.h", "ops": {}}
-    for op in range(nops):
+    ops = [int(x) for x in args.ops.split(",")] if args.ops else list(range(nops))
+    for op in ops:
         name = L.orbx_calibration_valu_name(op).decode()
         rows = {}
-        for w in (1, 2, 4, 8):
+        for w in [int(x) for x in args.waves.split(",")]:
             rate, cyc, clk = C.c_double(), C.c_double(), C.c_double()
             rc = L.orbx_calibration_valu(args.device, op, w, args.trips, C.byref(rate), C.byref(cyc), C.byref(clk))
             if rc != 0:
