@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -139,6 +139,8 @@ def load(build_if_needed=True):
     L.orbm_search_for_initialization.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp]
     L.orbm_fuse.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp]
     L.orbm_fuse_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp]
+    L.orbm_fuse_sim3_cam.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, vp, vp]
+    L.orbm_search_by_projection_sim3_cam.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, f32, vp, vp]
     L.orbm_search_by_sim3.argtypes = [vp] + [vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp] * 2 + [f32, vp, vp, vp, f32, vp]
     L.orbm_distinctive_descriptors.argtypes = [vp, i32, vp, vp, vp]
     L.orbm_knn_match2.argtypes = [vp, vp, i32, vp, i32, vp, vp]
@@ -644,7 +646,7 @@ class ORBmatcher:
             raise OrbError("orbm_fuse rc=%d" % rc)
         return rc, bi[:n], bd[:n]
 
-    def FuseSim3(self, KF, scale_factors, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Scw, cam, th=4.0):
+    def FuseSim3(self, KF, scale_factors, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Scw, cam, th=4.0, cam_type=0):
         """Search part of Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) -- ORBmatcher.cc:1660-1786."""
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
         sf = a(scale_factors, np.float32)
@@ -653,8 +655,8 @@ class ORBmatcher:
         n = len(valid)
         bi, bd = np.full(max(n, 1), -1, np.int32), np.full(max(n, 1), 256, np.int32)
         fs = KF.struct()
-        rc = self.L.orbm_fuse_sim3(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), n, _p(valid), _p(Xw), _p(normal), _p(mp_desc),
-                                   _p(max_dist), _p(min_dist), _p(Scw), _p(cam), C.c_float(th), _p(bi), _p(bd))
+        rc = self.L.orbm_fuse_sim3_cam(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), n, _p(valid), _p(Xw), _p(normal), _p(mp_desc),
+                                       _p(max_dist), _p(min_dist), _p(Scw), int(cam_type), _p(cam), C.c_float(th), _p(bi), _p(bd))
         self._check(rc, "orbm_fuse_sim3")
         if rc < 0:
             raise OrbError("orbm_fuse_sim3 rc=%d" % rc)
@@ -727,7 +729,7 @@ class ORBmatcher:
         return rc
 
     def SearchByProjectionSim3(self, KF, scale_factors, log_scale_factor, valid, Xw, normal, mp_desc, max_dist, min_dist, Scw, cam, th,
-                               ratioHamming=1.0):
+                               ratioHamming=1.0, cam_type=0):
         """SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th, ratioHamming) -- ORBmatcher.cc:489-720.
         KF is a FrameView of the keyframe's keypoints; KF.slot plays vpMatched."""
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
@@ -735,9 +737,9 @@ class ORBmatcher:
         valid, Xw, normal, mp_desc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mp_desc, np.uint8)
         max_dist, min_dist, Scw, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Scw, np.float32), a(cam, np.float32)
         fs = KF.struct()
-        rc = self.L.orbm_search_by_projection_sim3(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), len(valid), _p(valid),
-                                                   _p(Xw), _p(normal), _p(mp_desc), _p(max_dist), _p(min_dist), _p(Scw), _p(cam), int(th),
-                                                   C.c_float(ratioHamming), _p(KF.slot), _p(KF.slot_obs))
+        rc = self.L.orbm_search_by_projection_sim3_cam(self.m, C.byref(fs), _p(sf), len(sf), C.c_float(log_scale_factor), len(valid), _p(valid),
+                                                       _p(Xw), _p(normal), _p(mp_desc), _p(max_dist), _p(min_dist), _p(Scw), int(cam_type), _p(cam), int(th),
+                                                       C.c_float(ratioHamming), _p(KF.slot), _p(KF.slot_obs))
         self._check(rc, "orbm_search_by_projection_sim3")
         if rc < 0:
             raise OrbError("orbm_search_by_projection_sim3 rc=%d" % rc)

@@ -58,6 +58,20 @@ enum CalibOp {
   CAL_MUL_F32,        // v_mul_f32
   CAL_CVT_F32_U32,    // v_cvt_f32_u32
   CAL_ADD_CO_U32,     // v_add_co_u32 (carry out to VCC)
+  CAL_MINMAX_F32,     // v_min_f32 / v_max_f32
+  CAL_MIN3_F32,       // v_min3_f32
+  CAL_MAX3_F32,       // v_max3_f32
+  CAL_MED3_F32,       // v_med3_f32
+  CAL_PK_MINMAX_F16,  // v_pk_min_f16 / v_pk_max_f16
+  CAL_PK_FMA_F16,     // v_pk_fma_f16
+  CAL_PK_ADD_F16,     // v_pk_add_f16
+  CAL_MINMAX_F16,     // v_min_f16 / v_max_f16
+  CAL_MINMAX_U16,     // v_min_u16 / v_max_u16
+  CAL_CVT_UBYTE,      // v_cvt_f32_ubyte0
+  CAL_SUB_F32,        // v_sub_f32
+  CAL_MAX3_U32,       // v_max3_u32
+  CAL_PK_MINMAX_U16,  // v_pk_min_u16 / v_pk_max_u16
+  CAL_ADDC,           // v_addc_co_u32 (reads and writes VCC)
   CAL_NUM_OPS
 };
 
@@ -68,7 +82,8 @@ static const char *const kCalibOpNames[CAL_NUM_OPS] = {
     "k_fast score mix (4 pk_min:1 pk_max:1 pk_mad:2 add)", "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_sub_u32", "v_add3_u32",
     "v_and_or_b32", "v_lshl_or_b32", "v_bfe_u32", "v_min_i32/v_max_i32", "v_min3_u32", "v_med3_i32", "v_pk_add_u16", "v_pk_sub_i16", "v_sad_u8",
     "v_bitop3_b32", "v_cndmask_b32 (SGPR-pair mask)", "v_cndmask_b32 (vcc, scalar-written)", "v_add_f32", "v_mul_f32", "v_cvt_f32_u32",
-    "v_add_co_u32"};
+    "v_add_co_u32", "v_min_f32/v_max_f32", "v_min3_f32", "v_max3_f32", "v_med3_f32", "v_pk_min_f16/v_pk_max_f16", "v_pk_fma_f16", "v_pk_add_f16",
+    "v_min_f16/v_max_f16", "v_min_u16/v_max_u16", "v_cvt_f32_ubyte0", "v_sub_f32", "v_max3_u32", "v_pk_min_u16/v_pk_max_u16", "v_addc_co_u32"};
 
 #define CAL_INSTR_PER_TRIP 128
 
@@ -127,6 +142,25 @@ static const char *const kCalibOpNames[CAL_NUM_OPS] = {
 #define I_MULF(d) "v_mul_f32 %" #d ", %" #d ", %16\n"
 #define I_CVTF(d) "v_cvt_f32_u32 %" #d ", %" #d "\n"
 #define I_ADDCO(d) "v_add_co_u32 %" #d ", vcc, %" #d ", %16\n"
+#define I_MINF(d) "v_min_f32 %" #d ", %" #d ", %16\n"
+#define I_MAXF(d) "v_max_f32 %" #d ", %" #d ", %17\n"
+#define I_MIN3F(d) "v_min3_f32 %" #d ", %" #d ", %16, %17\n"
+#define I_MAX3F(d) "v_max3_f32 %" #d ", %" #d ", %16, %17\n"
+#define I_MED3F(d) "v_med3_f32 %" #d ", %" #d ", %16, %17\n"
+#define I_PKMINH(d) "v_pk_min_f16 %" #d ", %" #d ", %16\n"
+#define I_PKMAXH(d) "v_pk_max_f16 %" #d ", %" #d ", %17\n"
+#define I_PKFMAH(d) "v_pk_fma_f16 %" #d ", %" #d ", %16, %17\n"
+#define I_PKADDH(d) "v_pk_add_f16 %" #d ", %" #d ", %16\n"
+#define I_MINH(d) "v_min_f16 %" #d ", %" #d ", %16\n"
+#define I_MAXH(d) "v_max_f16 %" #d ", %" #d ", %17\n"
+#define I_MINU16(d) "v_min_u16 %" #d ", %" #d ", %16\n"
+#define I_MAXU16(d) "v_max_u16 %" #d ", %" #d ", %17\n"
+#define I_CVTUB(d) "v_cvt_f32_ubyte0 %" #d ", %" #d "\n"
+#define I_SUBF(d) "v_sub_f32 %" #d ", %" #d ", %16\n"
+#define I_MAX3U(d) "v_max3_u32 %" #d ", %" #d ", %16, %17\n"
+#define I_PKMINU(d) "v_pk_min_u16 %" #d ", %" #d ", %16\n"
+#define I_PKMAXU(d) "v_pk_max_u16 %" #d ", %" #d ", %17\n"
+#define I_ADDC(d) "v_addc_co_u32 %" #d ", vcc, %" #d ", %16, vcc\n"
 #define I_LSHLADD64(d) "v_lshl_add_u64 %" #d ", %" #d ", 1, %16\n"
 
 // stamps[block] = {shader-clock ticks, 100 MHz reference ticks} of the block's first wavefront around its loop
@@ -203,6 +237,20 @@ __global__ __launch_bounds__(256) void k_calib_valu(uint32_t *sink, unsigned lon
       if constexpr (OP == CAL_MUL_F32) asm volatile(CAL_TRIP(I_MULF) CAL_OPERANDS);
       if constexpr (OP == CAL_CVT_F32_U32) asm volatile(CAL_TRIP(I_CVTF) CAL_OPERANDS);
       if constexpr (OP == CAL_ADD_CO_U32) asm volatile(CAL_TRIP(I_ADDCO) CAL_OPERANDS);
+      if constexpr (OP == CAL_MINMAX_F32) asm volatile(CAL_TRIP2(I_MINF, I_MAXF) CAL_OPERANDS);
+      if constexpr (OP == CAL_MIN3_F32) asm volatile(CAL_TRIP(I_MIN3F) CAL_OPERANDS);
+      if constexpr (OP == CAL_MAX3_F32) asm volatile(CAL_TRIP(I_MAX3F) CAL_OPERANDS);
+      if constexpr (OP == CAL_MED3_F32) asm volatile(CAL_TRIP(I_MED3F) CAL_OPERANDS);
+      if constexpr (OP == CAL_PK_MINMAX_F16) asm volatile(CAL_TRIP2(I_PKMINH, I_PKMAXH) CAL_OPERANDS);
+      if constexpr (OP == CAL_PK_FMA_F16) asm volatile(CAL_TRIP(I_PKFMAH) CAL_OPERANDS);
+      if constexpr (OP == CAL_PK_ADD_F16) asm volatile(CAL_TRIP(I_PKADDH) CAL_OPERANDS);
+      if constexpr (OP == CAL_MINMAX_F16) asm volatile(CAL_TRIP2(I_MINH, I_MAXH) CAL_OPERANDS);
+      if constexpr (OP == CAL_MINMAX_U16) asm volatile(CAL_TRIP2(I_MINU16, I_MAXU16) CAL_OPERANDS);
+      if constexpr (OP == CAL_CVT_UBYTE) asm volatile(CAL_TRIP(I_CVTUB) CAL_OPERANDS);
+      if constexpr (OP == CAL_SUB_F32) asm volatile(CAL_TRIP(I_SUBF) CAL_OPERANDS);
+      if constexpr (OP == CAL_MAX3_U32) asm volatile(CAL_TRIP(I_MAX3U) CAL_OPERANDS);
+      if constexpr (OP == CAL_PK_MINMAX_U16) asm volatile(CAL_TRIP2(I_PKMINU, I_PKMAXU) CAL_OPERANDS);
+      if constexpr (OP == CAL_ADDC) asm volatile(CAL_TRIP(I_ADDC) CAL_OPERANDS);
       if constexpr (OP == CAL_FAST_MIX)
         asm volatile(CAL_R16(I_PKMIN) CAL_R16(I_PKMIN) CAL_R16(I_PKMAX) CAL_R16(I_PKMIN) CAL_R16(I_PKMAD) CAL_R16(I_PKMIN) CAL_R16(I_ADD)
                          CAL_R16(I_ADD) CAL_OPERANDS);

@@ -1598,7 +1598,15 @@ int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const floa
                                    const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
                                    const float *max_dist, const float *min_dist, const float *Scw, const float *cam, int th,
                                    float ratioHamming, int32_t *slot, uint8_t *slot_obs) {
-  if (!m || !kf || !sf || nlevels < 1 || nP < 0 || !Scw || !cam || !slot || !slot_obs) return ORBX_E_ARG;
+  return orbm_search_by_projection_sim3_cam(m, kf, sf, nlevels, logScaleFactor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, 0, cam, th,
+                                            ratioHamming, slot, slot_obs);
+}
+
+int orbm_search_by_projection_sim3_cam(orbm_t *m, const orbm_frame_t *kf, const float *sf, int nlevels, float logScaleFactor, int nP,
+                                       const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                                       const float *max_dist, const float *min_dist, const float *Scw, int cam_type, const float *cam, int th,
+                                       float ratioHamming, int32_t *slot, uint8_t *slot_obs) {
+  if (!m || !kf || !sf || nlevels < 1 || nP < 0 || !Scw || !cam || !slot || !slot_obs || (cam_type != 0 && cam_type != 1)) return ORBX_E_ARG;
   if (nP > 0 && (!valid || !Xw || !normal || !mpdesc || !max_dist || !min_dist)) return ORBX_E_ARG;
   // Decompose Scw, :498-503: scw = sqrt(row0 . row0) (Mat::dot accumulates in double); Rcw = sRcw/scw, tcw = t/scw
   double dot = 0;
@@ -1627,7 +1635,7 @@ int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const floa
     mat3_mul_add(T, p3Dw, tcw, p3Dc);                                         // :523
     if ((double)p3Dc[2] < 0.0) continue;                                      // :526
     float ux, vy;
-    orbm_project(0, cam, p3Dc[0], p3Dc[1], p3Dc[2], &ux, &vy);                // :534
+    orbm_project(cam_type, cam, p3Dc[0], p3Dc[1], p3Dc[2], &ux, &vy);         // :534, pKF->mpCamera->project
     if (!(ux >= kf->min_x && ux < kf->max_x && vy >= kf->min_y && vy < kf->max_y)) continue;  // KeyFrame::IsInImage, KeyFrame.cc:844-847
     float PO[3];
     double n2 = 0, pd = 0;
@@ -1726,7 +1734,14 @@ int orbm_fuse(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, con
 int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
                    const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
                    const float *min_dist, const float *Scw, const float *cam, float th, int32_t *best_idx, int32_t *best_dist) {
-  if (!m || !kf || !scale_factors || nlevels < 1 || nP < 0 || !Scw || !cam || !best_idx || !best_dist) return ORBX_E_ARG;
+  return orbm_fuse_sim3_cam(m, kf, scale_factors, nlevels, log_scale_factor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, 0, cam, th,
+                            best_idx, best_dist);
+}
+
+int orbm_fuse_sim3_cam(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
+                       const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                       const float *min_dist, const float *Scw, int cam_type, const float *cam, float th, int32_t *best_idx, int32_t *best_dist) {
+  if (!m || !kf || !scale_factors || nlevels < 1 || nP < 0 || !Scw || !cam || !best_idx || !best_dist || (cam_type != 0 && cam_type != 1)) return ORBX_E_ARG;
   if (nP > 0 && (!valid || !Xw || !normal || !mpdesc || !max_dist || !min_dist)) return ORBX_E_ARG;
   if (nP == 0) return 0;
   // Decompose Scw, :1668-1673 (as in orbm_search_by_projection_sim3)
@@ -1746,7 +1761,7 @@ int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors
     for (int k = 0; k < 3; k++) acc += (double)T[4 * k + i] * (double)tcw[k];
     Ow[i] = (float)(-acc);
   }
-  return fuse_core(m, kf, scale_factors, nullptr, nlevels, log_scale_factor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, T, Ow, 0, cam,
+  return fuse_core(m, kf, scale_factors, nullptr, nlevels, log_scale_factor, nP, valid, Xw, normal, mpdesc, max_dist, min_dist, T, Ow, cam_type, cam,
                    0.f, th, false, best_idx, best_dist);
 }
 

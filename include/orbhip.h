@@ -334,6 +334,13 @@ int orbm_search_by_projection_sim3(orbm_t *m, const orbm_frame_t *kf, const floa
                                    const float *min_dist, const float *Scw, const float *cam, int th,
                                    float ratioHamming, int32_t *slot, uint8_t *slot_obs);
 
+/* The same member for any camera model of the keyframe (pKF->mpCamera->project, :534): cam_type / cam_params as in orbm_project.
+ * orbm_search_by_projection_sim3 is this with cam_type 0. */
+int orbm_search_by_projection_sim3_cam(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
+                                       const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                                       const float *max_dist, const float *min_dist, const float *Scw, int cam_type, const float *cam_params,
+                                       int th, float ratioHamming, int32_t *slot, uint8_t *slot_obs);
+
 /* int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th, const bool bRight = false)
  *                                                                                             (ORBmatcher.cc:1425-1658)
  * kf = the keyframe's mvKeysUn / mDescriptors / mvuRight (NULL = all -1) / image bounds; i in [0, nP): valid[i] =
@@ -353,6 +360,12 @@ int orbm_fuse(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, con
 int orbm_fuse_sim3(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
                    const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
                    const float *min_dist, const float *Scw, const float *cam, float th, int32_t *best_idx, int32_t *best_dist);
+
+/* ... for any camera model (pKF->mpCamera->project, :1704); orbm_fuse_sim3 is this with cam_type 0. */
+int orbm_fuse_sim3_cam(orbm_t *m, const orbm_frame_t *kf, const float *scale_factors, int nlevels, float log_scale_factor, int nP,
+                       const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc, const float *max_dist,
+                       const float *min_dist, const float *Scw, int cam_type, const float *cam_params, float th, int32_t *best_idx,
+                       int32_t *best_dist);
 
 /* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12,
  *                              const cv::Mat &R12, const cv::Mat &t12, const float th)           (ORBmatcher.cc:1788-2012)

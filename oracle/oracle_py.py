@@ -419,15 +419,15 @@ def search_by_projection_kf(F, valid, Xw, mpdesc, kf_angle, max_dist, min_dist, 
                                          int(check_ori), _p(F.slot), _p(F.slot_obs))
 
 
-def search_by_projection_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th, ratio_hamming):
+def search_by_projection_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th, ratio_hamming, cam_type=0):
     """M5 on an OracleFrame holding the KeyFrame's keypoints (ORBmatcher.cc:489-602); slot/slot_obs updated in place."""
     a = lambda x, t: np.ascontiguousarray(x, dtype=t)
     valid, Xw, normal, mpdesc = a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mpdesc, np.uint8)
     max_dist, min_dist, Scw, cam = a(max_dist, np.float32), a(min_dist, np.float32), a(Scw, np.float32), a(cam, np.float32)
     L = lib()
-    L.orc_search_by_projection_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
-    return L.orc_search_by_projection_sim3(C.byref(F.f), len(valid), _p(valid), _p(Xw), _p(normal), _p(mpdesc), _p(max_dist), _p(min_dist),
-                                           _p(Scw), _p(cam), C.c_float(log_scale_factor), int(th), C.c_float(ratio_hamming), _p(F.slot), _p(F.slot_obs))
+    L.orc_search_by_projection_sim3_cam.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    return L.orc_search_by_projection_sim3_cam(C.byref(F.f), len(valid), _p(valid), _p(Xw), _p(normal), _p(mpdesc), _p(max_dist), _p(min_dist),
+                                               _p(Scw), int(cam_type), _p(cam), C.c_float(log_scale_factor), int(th), C.c_float(ratio_hamming), _p(F.slot), _p(F.slot_obs))
 
 
 def fuse(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Tcw, Ow, cam_type, cam, bf, inv_sigma2, log_scale_factor, th):
@@ -445,16 +445,17 @@ def fuse(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Tcw, Ow, cam_type, ca
     return nf, bi, bd
 
 
-def fuse_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th):
+def fuse_sim3(F, valid, Xw, normal, mpdesc, max_dist, min_dist, Scw, cam, log_scale_factor, th, cam_type=0):
     """Search part of Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:1660-1786)."""
     a = lambda x, t: np.ascontiguousarray(x, dtype=t)
     n = len(valid)
     bi, bd = np.full(n, -1, np.int32), np.full(n, 256, np.int32)
     L = lib()
-    L.orc_fuse_sim3.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_fuse_sim3_cam.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     args = [a(valid, np.uint8), a(Xw, np.float32), a(normal, np.float32), a(mpdesc, np.uint8), a(max_dist, np.float32), a(min_dist, np.float32),
-            a(Scw, np.float32), a(cam, np.float32)]
-    nf = L.orc_fuse_sim3(C.byref(F.f), n, *[_p(x) for x in args], C.c_float(log_scale_factor), C.c_float(th), _p(bi), _p(bd))
+            a(Scw, np.float32)]
+    cam = a(cam, np.float32)
+    nf = L.orc_fuse_sim3_cam(C.byref(F.f), n, *[_p(x) for x in args], int(cam_type), _p(cam), C.c_float(log_scale_factor), C.c_float(th), _p(bi), _p(bd))
     return nf, bi, bd
 
 

@@ -1769,6 +1769,13 @@ int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, c
                                   const uint8_t *mpdesc, const float *maxDist, const float *minDist, const float *Scw,
                                   const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
                                   uint8_t *slot_obs) {
+  return orc_search_by_projection_sim3_cam(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Scw, 0, cam, logScaleFactor, th, ratioHamming, slot, slot_obs);
+}
+/* pKF->mpCamera->project (:534) for either camera model */
+int orc_search_by_projection_sim3_cam(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal,
+                                      const uint8_t *mpdesc, const float *maxDist, const float *minDist, const float *Scw, int camType,
+                                      const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
+                                      uint8_t *slot_obs) {
   /* Decompose Scw (:498-503): Mat::dot accumulates in double; Mat / float = convert with scale 1./s in double */
   double dot = 0;
   for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
@@ -1793,7 +1800,7 @@ int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, c
     mat3_mul_add(Rcw, 3, p3Dw, tcw, p3Dc);
     if ((double)p3Dc[2] < 0.0) continue;
     float uvx, uvy;
-    orc_project(0, cam, p3Dc[0], p3Dc[1], p3Dc[2], &uvx, &uvy);
+    orc_project(camType, cam, p3Dc[0], p3Dc[1], p3Dc[2], &uvx, &uvy);
     if (!(uvx >= kf->mnMinX && uvx < kf->mnMaxX && uvy >= kf->mnMinY && uvy < kf->mnMaxY)) continue; /* KeyFrame::IsInImage */
     const float maxDistance = 1.2f * maxDist[iMP], minDistance = 0.8f * minDist[iMP];
     float PO[3];
@@ -2101,6 +2108,11 @@ int orc_fuse(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const
 int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
                   const float *maxDist, const float *minDist, const float *Scw, const float *cam, float logScaleFactor, float th,
                   int32_t *bestIdx, int32_t *bestDist) {
+  return orc_fuse_sim3_cam(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Scw, 0, cam, logScaleFactor, th, bestIdx, bestDist);
+}
+int orc_fuse_sim3_cam(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                      const float *maxDist, const float *minDist, const float *Scw, int camType, const float *cam, float logScaleFactor, float th,
+                      int32_t *bestIdx, int32_t *bestDist) {
   double dot = 0;
   for (int k = 0; k < 3; k++) dot += (double)Scw[k] * (double)Scw[k];
   const float scw = (float)sqrt(dot);
@@ -2115,7 +2127,7 @@ int orc_fuse_sim3(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, 
     for (int k = 0; k < 3; k++) sacc += (double)Rcw[k * 3 + i] * (double)tcw[k];
     Ow[i] = (float)(sacc * -1.0);
   }
-  return fuse_impl(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Rcw, tcw, Ow, 0, cam, 0.f, NULL, logScaleFactor, th, 0, bestIdx, bestDist);
+  return fuse_impl(kf, nP, valid, Xw, normal, mpdesc, maxDist, minDist, Rcw, tcw, Ow, camType, cam, 0.f, NULL, logScaleFactor, th, 0, bestIdx, bestDist);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -248,6 +248,15 @@ int orc_search_by_projection_sim3(orc_frame *kf, int nP, const uint8_t *valid, c
                                   const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
                                   uint8_t *slot_obs);
 
+/* M5 / Fuse(Sim3) with the keyframe's own camera model (pKF->mpCamera->project): camType as in orc_project. */
+int orc_search_by_projection_sim3_cam(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal,
+                                      const uint8_t *mpdesc, const float *maxDist, const float *minDist, const float *Scw, int camType,
+                                      const float *cam, float logScaleFactor, int th, float ratioHamming, int32_t *slot,
+                                      uint8_t *slot_obs);
+int orc_fuse_sim3_cam(orc_frame *kf, int nP, const uint8_t *valid, const float *Xw, const float *normal, const uint8_t *mpdesc,
+                      const float *maxDist, const float *minDist, const float *Scw, int camType, const float *cam, float logScaleFactor, float th,
+                      int32_t *bestIdx, int32_t *bestDist);
+
 /* G0: Frame::UndistortKeyPoints (Frame.cc:837-870) / ComputeImageBounds (:872-899) =
  * cv::undistortPoints(src, dst, K, D=(k1,k2,p1,p2[,k3]), R=I, P=K) restated from SURVEY.md A.9: per point in double,
  * 5 fixed-point iterations, result stored as float.  K = [fx,fy,cx,cy]; D has nD = 4 or 5 coefficients.

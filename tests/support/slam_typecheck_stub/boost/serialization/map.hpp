@@ -1,0 +1,1 @@
+#include "boost_double.h"

@@ -1,0 +1,1 @@
+#include "cv_double.h"

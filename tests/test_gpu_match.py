@@ -264,14 +264,15 @@ def test_search_by_projection_keyframe_m4(pkg, oracle, synth, matcher, cam):
         assert n_gpu == n_ref
         assert np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
         total += n_ref
-    assert total > (100 if cam == 0 else 0)
+    assert total > (100 if cam == 0 else 300)
 
 
+@pytest.mark.parametrize("cam", [0, 1])
 @pytest.mark.parametrize("ratio", [1.0, 0.75])
-def test_search_by_projection_sim3_m5(pkg, oracle, synth, matcher, ratio):
+def test_search_by_projection_sim3_m5(pkg, oracle, synth, matcher, ratio, cam):
     """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) -- loop closing: Sim3
     decomposition, IsInImage (half-open), depth-range and viewing-angle gates, PredictScale, [lvl-1, lvl] window."""
-    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3500, 0, False)
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3500 + cam, cam, False)   # cam 1: pKF->mpCamera is KannalaBrandt8
     rng = np.random.default_rng(31)
     bounds = (0.0, 752.0, 0.0, 480.0)
     scale = np.float32(1.37)
@@ -288,8 +289,8 @@ def test_search_by_projection_sim3_m5(pkg, oracle, synth, matcher, ratio):
     OKF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
     occ = rng.random(len(k1)) < 0.2
     KF.slot[occ] = 1 << 30; KF.slot_obs[occ] = 1; OKF.slot[occ] = 1 << 30; OKF.slot_obs[occ] = 1
-    n_gpu = matcher.SearchByProjectionSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 8, ratio)
-    n_ref = oracle.search_by_projection_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 8, ratio)
+    n_gpu = matcher.SearchByProjectionSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 8, ratio, cam_type=cam)
+    n_ref = oracle.search_by_projection_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 8, ratio, cam_type=cam)
     assert n_gpu == n_ref and n_ref > 100
     assert np.array_equal(KF.slot, OKF.slot) and np.array_equal(KF.slot_obs, OKF.slot_obs)
 
@@ -528,9 +529,10 @@ def test_fuse_n3(pkg, oracle, synth, matcher, cam, stereo):
     assert total > (100 if (cam == 0 and not stereo) else 20 if cam == 0 else 0)   # the 3-term chi-square gate is tight in the stereo scene
 
 
-def test_fuse_sim3_n3(pkg, oracle, synth, matcher):
+@pytest.mark.parametrize("cam", [0, 1])
+def test_fuse_sim3_n3(pkg, oracle, synth, matcher, cam):
     """ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) search part (ORBmatcher.cc:1660-1766)."""
-    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3960, 0, False)
+    k0, d0, k1, d1, sf, Xw, Tcw, Tlw, has_mp, obs, params, _ = _m3_scene(pkg, oracle, synth, 3960 + cam, cam, False)
     rng = np.random.default_rng(43)
     bounds = (0.0, 752.0, 0.0, 480.0)
     Scw = Tcw.copy()
@@ -543,8 +545,8 @@ def test_fuse_sim3_n3(pkg, oracle, synth, matcher):
     log_sf = float(np.log(np.float32(1.2)))
     KF = pkg.FrameView(k1, d1, bounds)
     OKF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf)
-    n_gpu, bi_gpu, bd_gpu = matcher.FuseSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 4.0)
-    n_ref, bi_ref, bd_ref = oracle.fuse_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 4.0)
+    n_gpu, bi_gpu, bd_gpu = matcher.FuseSim3(KF, sf, log_sf, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, 4.0, cam_type=cam)
+    n_ref, bi_ref, bd_ref = oracle.fuse_sim3(OKF, has_mp, Xw, normal, d0, max_dist, min_dist, Scw, params, log_sf, 4.0, cam_type=cam)
     assert n_gpu == n_ref and n_ref > 100
     assert np.array_equal(bi_gpu, bi_ref) and np.array_equal(bd_gpu, bd_ref)
 
