@@ -72,6 +72,9 @@ enum CalibOp {
   CAL_MAX3_U32,       // v_max3_u32
   CAL_PK_MINMAX_U16,  // v_pk_min_u16 / v_pk_max_u16
   CAL_ADDC,           // v_addc_co_u32 (reads and writes VCC)
+  CAL_SALU_ADD,       // s_add_u32 (scalar unit: one per CU?)
+  CAL_SALU_AND64,     // s_and_b64 / s_bcnt1_i32_b64 (the mask arithmetic around ballots)
+  CAL_DS_READ_U8,     // ds_read_u8 with a per-lane address (LDS issue rate as k_fast's gathers see it)
   CAL_NUM_OPS
 };
 
@@ -83,7 +86,8 @@ static const char *const kCalibOpNames[CAL_NUM_OPS] = {
     "v_and_or_b32", "v_lshl_or_b32", "v_bfe_u32", "v_min_i32/v_max_i32", "v_min3_u32", "v_med3_i32", "v_pk_add_u16", "v_pk_sub_i16", "v_sad_u8",
     "v_bitop3_b32", "v_cndmask_b32 (SGPR-pair mask)", "v_cndmask_b32 (vcc, scalar-written)", "v_add_f32", "v_mul_f32", "v_cvt_f32_u32",
     "v_add_co_u32", "v_min_f32/v_max_f32", "v_min3_f32", "v_max3_f32", "v_med3_f32", "v_pk_min_f16/v_pk_max_f16", "v_pk_fma_f16", "v_pk_add_f16",
-    "v_min_f16/v_max_f16", "v_min_u16/v_max_u16", "v_cvt_f32_ubyte0", "v_sub_f32", "v_max3_u32", "v_pk_min_u16/v_pk_max_u16", "v_addc_co_u32"};
+    "v_min_f16/v_max_f16", "v_min_u16/v_max_u16", "v_cvt_f32_ubyte0", "v_sub_f32", "v_max3_u32", "v_pk_min_u16/v_pk_max_u16", "v_addc_co_u32",
+    "s_add_u32", "s_and_b64/s_bcnt1_i32_b64", "ds_read_u8"};
 
 #define CAL_INSTR_PER_TRIP 128
 
@@ -251,6 +255,30 @@ __global__ __launch_bounds__(256) void k_calib_valu(uint32_t *sink, unsigned lon
       if constexpr (OP == CAL_MAX3_U32) asm volatile(CAL_TRIP(I_MAX3U) CAL_OPERANDS);
       if constexpr (OP == CAL_PK_MINMAX_U16) asm volatile(CAL_TRIP2(I_PKMINU, I_PKMAXU) CAL_OPERANDS);
       if constexpr (OP == CAL_ADDC) asm volatile(CAL_TRIP(I_ADDC) CAL_OPERANDS);
+      if constexpr (OP == CAL_SALU_ADD)
+        asm volatile(
+#define S8 "s_add_u32 s20, s20, 1\ns_add_u32 s21, s21, 1\ns_add_u32 s22, s22, 1\ns_add_u32 s23, s23, 1\ns_add_u32 s24, s24, 1\ns_add_u32 s25, s25, 1\ns_add_u32 s26, s26, 1\ns_add_u32 s27, s27, 1\n"
+            S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8
+#undef S8
+            CAL_OPERANDS, "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
+      if constexpr (OP == CAL_SALU_AND64)
+        asm volatile(
+#define S8 "s_and_b64 s[20:21], s[20:21], exec\ns_bcnt1_i32_b64 s24, s[20:21]\ns_and_b64 s[22:23], s[22:23], exec\ns_bcnt1_i32_b64 s25, s[22:23]\ns_and_b64 s[26:27], s[26:27], exec\ns_bcnt1_i32_b64 s28, s[26:27]\ns_and_b64 s[30:31], s[30:31], exec\ns_bcnt1_i32_b64 s29, s[30:31]\n"
+            S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8 S8
+#undef S8
+            CAL_OPERANDS, "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "scc");
+      if constexpr (OP == CAL_DS_READ_U8) {
+        // 128 byte gathers per trip from the first 16 KiB of the workgroup's LDS (contents irrelevant), 16 in flight
+        const uint32_t base = (a & 0x3fffu);
+        asm volatile(
+#define D16 "ds_read_u8 %0, %16\nds_read_u8 %1, %16 offset:80\nds_read_u8 %2, %16 offset:160\nds_read_u8 %3, %16 offset:240\nds_read_u8 %4, %16 offset:3\nds_read_u8 %5, %16 offset:83\nds_read_u8 %6, %16 offset:163\nds_read_u8 %7, %16 offset:243\nds_read_u8 %8, %16 offset:320\nds_read_u8 %9, %16 offset:400\nds_read_u8 %10, %16 offset:480\nds_read_u8 %11, %16 offset:560\nds_read_u8 %12, %16 offset:323\nds_read_u8 %13, %16 offset:403\nds_read_u8 %14, %16 offset:483\nds_read_u8 %15, %16 offset:563\ns_waitcnt lgkmcnt(0)\n"
+            D16 D16 D16 D16 D16 D16 D16 D16
+#undef D16
+            : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]),
+              "=v"(r[11]), "=v"(r[12]), "=v"(r[13]), "=v"(r[14]), "=v"(r[15])
+            : "v"(base), "v"(b)
+            : "memory");
+      }
       if constexpr (OP == CAL_FAST_MIX)
         asm volatile(CAL_R16(I_PKMIN) CAL_R16(I_PKMIN) CAL_R16(I_PKMAX) CAL_R16(I_PKMIN) CAL_R16(I_PKMAD) CAL_R16(I_PKMIN) CAL_R16(I_ADD)
                          CAL_R16(I_ADD) CAL_OPERANDS);

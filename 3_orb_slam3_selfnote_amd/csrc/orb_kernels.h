@@ -267,6 +267,10 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
 // "any corner at iniTh" vote and for the raster-order compaction.  Output: per-cell slot list, packed
 // (response<<24 | y<<12 | x) in detection-rectangle coordinates, raster order inside the cell.
 // ------------------------------------------------------------------------------------------------------------
+// number of set bits of a wave ballot below this lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int lane_rank(unsigned long long b) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
 typedef short pk16 __attribute__((ext_vector_type(2)));  // two signed 16-bit lanes in one VGPR (v_pk_*_i16)
 __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pitch FAST_TILE_PITCH */) {
   constexpr int Pt = FAST_TILE_PITCH;
@@ -300,7 +304,7 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
 // circle pixels contains two ADJACENT compass pixels, so two adjacent ones must both be darker than v-t or both
 // brighter than v+t.  Pixels that fail it at minThFAST have S <= minThFAST and can never be emitted nor suppress a
 // neighbour, so their score is left at 0 and the 16-pixel score is only evaluated for the survivors.
-__device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
+__device__ __forceinline__ int fast_compass_sign(const uint8_t *c, int t) {  // negative <=> the pixel passes
   // sign-bit arithmetic (no compare -> select chains, which cost SGPR hazards and scalar mask ops)
   constexpr int Pt = FAST_TILE_PITCH;
   const int v = c[0];
@@ -311,7 +315,7 @@ __device__ __forceinline__ bool fast_compass_test(const uint8_t *c, int t) {
   // two ADJACENT compass pixels both dark: (d0&d4)|(d4&d8)|(d8&d12)|(d12&d0) = (d0|d8) & (d4|d12) on the sign bits
   const int dd = (d0 | d8) & (d4 | d12);
   const int bb = (b0 | b8) & (b4 | b12);
-  return (dd | bb) < 0;
+  return dd | bb;
 }
 
 #ifndef FAST_NT
@@ -326,6 +330,13 @@ __device__ unsigned int *g_fast_stamps;  // [workgroup][8] cycle deltas, set by 
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
+// Diagnostic builds (-DFAST_STOP=n): the kernel ends after section n, so that rocprofv3's per-kernel counters of successive
+// builds give each section's instruction counts by difference (tools/fast_sections.sh).  Never defined in the product build.
+#ifdef FAST_STOP
+#define FSTOP(i) do { if (FAST_STOP == (i)) { __syncthreads(); if (threadIdx.x == 0) *cellCnt = (sList[P.iniTh & 3] + sS[P.minTh & 3] + sKept[P.lap0 & 3] + sT[P.lap1 & 3] + sWCount[P.lap0 & 3]) == 0x7fffffffu ? 1u : 0u; return; } } while (0)
+#else
+#define FSTOP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 #ifdef FAST_STAMPS
   long long ft0 = __builtin_readcyclecounter();
@@ -334,8 +345,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   __shared__ uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[4 * FAST_LIST_SEG];
   __shared__ uint32_t sKept[900];   // strict 3x3 maxima: at most ceil(cw/2) * ceil(ch/2) <= 30 * 30
-  __shared__ uint32_t sCount, sNKept, sNOut;
-  __shared__ __align__(16) uint32_t sWCount[4];
+  __shared__ __align__(16) uint32_t sWCount[12];   // [0..3] pass-1 list segments, [4..11] two count buffers of the ordered compactions
   const int tid = threadIdx.x, lane = tid & 63;
   int cellId, frame;
   xcd_map(P.totalCells, P.magicCells, P.nframes, frame, cellId);
@@ -380,33 +390,59 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     }
   }
   for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
-  if (tid == 0) { sCount = 0; sNKept = 0; sNOut = 0; }
   __syncthreads();
   FSTAMP(0);
+  FSTOP(0);
   const int tmin = min(P.iniTh, P.minTh);
   // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list as y << 6 | x (raster order = numeric order).
   // Threads form rows of 32 (cells up to 32 interior columns, the usual 30) or 64 lanes and step down the cell, so the
   // per-pixel index arithmetic is one add; a linear pixel index would need a division per pixel.
+  // Wavefront w owns the CONTIGUOUS rows [w * R, (w + 1) * R), R = ceil(ch / 4): its list segment is in raster order and so
+  // is the concatenation of the four segments - every later pass can keep that order with ballots and never has to sort.
   const int xsh = cw <= 32 ? 5 : 6;
-  const int px = tid & ((1 << xsh) - 1), py = tid >> xsh, yStep = FAST_NT >> xsh;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction; tells the compiler so (scalar loop bounds)
+  const int px = lane & ((1 << xsh) - 1), sub = lane >> xsh, rpi = 64 >> xsh;   // rows per wave-instruction: 2 or 1
+  const int R = (ch + 3) >> 2;
+  const int rowBeg = wave * R, rowEnd = min(rowBeg + R, ch);
   const bool xin = px < cw;
-  const uint8_t *c0 = &sT[(py + 3) * FAST_TILE_PITCH + ox + px + 3];
-  // Every wavefront appends to its own segment of the list (at most ceil(ch / yStep) rows x cw entries <= FAST_LIST_SEG) and
+  // Every wavefront appends to its own segment of the list (at most R rows x cw entries <= 15 x 59 <= FAST_LIST_SEG) and
   // keeps its count in a scalar register: no atomics.
-  uint16_t *myList = sList + (tid >> 6) * FAST_LIST_SEG;
-  const unsigned long long laneLt = (1ull << lane) - 1ull;
+  uint16_t *myList = sList + wave * FAST_LIST_SEG;
   int wcount = 0;
-  for (int y0 = 0; y0 < ch; y0 += yStep) {
-    const int y = y0 + py;
-    // lanes outside the cell read LDS bytes that mean nothing (or zero past the allocation) and are masked out afterwards
-    const bool pass = fast_compass_test(c0 + y0 * FAST_TILE_PITCH, tmin) & xin & (y < ch);
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(pass);
-    if (pass) myList[wcount + __popcll(b & laneLt)] = (uint16_t)((y << 6) | px);
-    wcount += __popcll(b);
+  {
+    const uint8_t *c = &sT[(rowBeg + sub + 3) * FAST_TILE_PITCH + ox + px + 3];
+    int yv = ((rowBeg + sub) << 6) | px;
+    // validity as a sign bit: row - rowEnd is negative inside the wavefront's rows; columns outside the cell start from a value
+    // that stays positive.  The pass condition is then ONE integer compare, which is also the ballot (no select / re-compare).
+    int yr = xin ? rowBeg + sub - rowEnd : 0x40000000;
+    for (int y0 = rowBeg; y0 < rowEnd; y0 += rpi, c += rpi * FAST_TILE_PITCH, yv += rpi << 6, yr += rpi) {
+      // lanes outside the cell read LDS bytes that mean nothing (or zero past the allocation) and are masked out by yr
+#ifdef FAST_PAD   // diagnostic builds only (tools/fast_sensitivity.sh): 16 extra instructions of one class per pass-1 trip, results unused
+      {
+        int pad0 = yv, pad1 = yr;
+#if FAST_PAD == 1   // full-rate VALU
+        asm volatile("v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
+#elif FAST_PAD == 2   // half-rate VALU
+        asm volatile("v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n"
+                     "v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
+#elif FAST_PAD == 3   // scalar ALU
+        asm volatile("s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n"
+                     "s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n" ::: "s40", "s41", "s42", "s43", "scc");
+#endif
+        asm volatile("" ::"v"(pad0), "v"(pad1));
+      }
+#endif
+      const bool pass = (fast_compass_sign(c, tmin) & yr) < 0;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(pass);
+      if (pass) myList[wcount + lane_rank(b)] = (uint16_t)yv;
+      wcount += __popcll(b);
+    }
   }
-  if (lane == 0) sWCount[tid >> 6] = (uint32_t)wcount;
+  if (lane == 0) sWCount[wave] = (uint32_t)wcount;
   __syncthreads();
   FSTAMP(1);
+  FSTOP(1);
   // The four segments are walked as one list by all 256 threads (a wavefront walking only its own segment would need a
   // second trip whenever that segment alone exceeds 64 entries): entry e lives in segment #(prefix sums <= e).
   const uint4 wc = *reinterpret_cast<const uint4 *>(sWCount);
@@ -425,43 +461,61 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   }
   __syncthreads();
   FSTAMP(2);
-  // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list; vote for
-  // the iniThFAST set.  Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
-  for (int e = tid; e < nlist; e += FAST_NT) {
-    const int p = entry(e);
-    const int y = p >> 6, x = p & 63;
-    const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
-    const int S = s[0];
-    const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
-    const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
-    const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
-    const bool keep = (S > tmin) & (S >= 2) & (S > m2);
-    if (keep) {
-      sKept[atomicAdd(&sNKept, 1u)] = (uint32_t)p | ((uint32_t)S << 16);  // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
-      if (S > P.iniTh) sCount = 1;                                        // benign race: every writer stores 1
+  FSTOP(2);
+  // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list in raster order.
+  // Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
+  // The per-cell threshold fallback (ORBextractor.cc:825-828) is decided after NMS: the cell emits A = {kept, S > iniThFAST} if
+  // that set is not empty, else {kept, S > minThFAST}.  With minThFAST <= iniThFAST every kept entry is in the second set, so
+  // an entry needs two ranks: its position in the kept list and its rank inside A.  Both come from order-preserving
+  // compactions of the same 256-entry chunk: a ballot + lane rank inside a wavefront, the four wavefronts' counts (packed,
+  // 10 bits each) through LDS - two count buffers in turn, so one barrier per chunk.  No atomics, no sorting afterwards.
+  uint32_t *sCnt2 = sWCount + 4;   // [2][4]
+  int turn = 0, nkept = 0, nA = 0;
+  for (int e0 = 0; e0 < nlist; e0 += FAST_NT) {
+    const int e = e0 + tid;
+    bool keep = false, inA = false;
+    uint32_t kv = 0;
+    if (e < nlist) {
+      const int p = entry(e);
+      const int y = p >> 6, x = p & 63;
+      const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
+      const int S = s[0];
+      const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
+      const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
+      const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
+      keep = (S > tmin) & (S >= 2) & (S > m2);
+      inA = keep & (S > P.iniTh);
+      kv = (uint32_t)p | ((uint32_t)S << 12);
     }
+    const unsigned long long bK = __builtin_amdgcn_ballot_w64(keep), bA = __builtin_amdgcn_ballot_w64(inA);
+    uint32_t *cnt = sCnt2 + 4 * turn;
+    turn ^= 1;
+    if (lane == 0) cnt[wave] = (uint32_t)__popcll(bK) | ((uint32_t)__popcll(bA) << 10);
+    __syncthreads();
+    const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt);
+    const uint32_t pre = (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);   // fields stay below 1024
+    const uint32_t tot = c4.x + c4.y + c4.z + c4.w;
+    if (keep) {                                                            // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
+      const uint32_t rankA = (uint32_t)nA + (pre >> 10) + (uint32_t)lane_rank(bA);
+      sKept[nkept + (int)(pre & 1023u) + lane_rank(bK)] = kv | (rankA << 20);
+    }
+    nkept += (int)(tot & 1023u);
+    nA += (int)(tot >> 10);
   }
   __syncthreads();
   FSTAMP(3);
-  const int thr = sCount ? P.iniTh : P.minTh;  // per-cell fallback, decided after NMS (ORBextractor.cc:825-828)
-  uint32_t *sOut = reinterpret_cast<uint32_t *>(sT);  // the tile is dead after pass 2 (5280 B >= 900 entries): keeps LDS below 20 KB = 8 workgroups per CU
-  const int nkept = (int)sNKept;
-  for (int e = tid; e < nkept; e += FAST_NT) {
-    const uint32_t v = sKept[e];
-    if ((int)(v >> 16) > thr) sOut[atomicAdd(&sNOut, 1u)] = v;
-  }
-  __syncthreads();
-  FSTAMP(4);
-  // ---- pass 4: cv::FAST emits rows ascending, x ascending = ascending p: rank by counting (lists are short)
-  const int nout = (int)sNOut;
+  FSTOP(3);
+  // ---- pass 4: cv::FAST emits rows ascending, x ascending = the kept list's own order: every keypoint goes to its rank.
+  const bool useA = nA > 0 && P.minTh <= P.iniTh;   // (minThFAST > iniThFAST: every kept entry already exceeds iniThFAST = tmin)
+  const int nout = useA ? nA : nkept;
   uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
-  for (int e = tid; e < nout; e += FAST_NT) {
-    const uint32_t v = sOut[e], p = v & 0xffffu;
-    uint32_t rank = 0;
-    for (int i = 0; i < nout; i++) rank += ((sOut[i] & 0xffffu) < p) ? 1u : 0u;
-    const int y = (int)(p >> 6), x = (int)(p & 63u);
-    const uint32_t X = baseX + (uint32_t)(x + 3), Y = baseY + (uint32_t)(y + 3);
-    if (rank < cellCap) slots[rank] = (((v >> 16) - 1u) << 24) | (Y << 12) | X;
+  for (int e = tid; e < nkept; e += FAST_NT) {
+    const uint32_t v = sKept[e], S = (v >> 12) & 255u;
+    const uint32_t rank = useA ? (v >> 20) : (uint32_t)e;
+    if ((!useA || (int)S > P.iniTh) && rank < cellCap) {
+      const uint32_t X = baseX + (v & 63u) + 3u, Y = baseY + ((v >> 6) & 63u) + 3u;
+      slots[rank] = ((S - 1u) << 24) | (Y << 12) | X;
+    }
   }
   if (tid == 0) *cellCnt = min((uint32_t)nout, cellCap);
   FSTAMP(7);

@@ -98,6 +98,20 @@ def launch_ranks(args, argv):
     return max((abs(rc) for rc in rcs), default=0)
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU box hands
+    each job a 16-core share of a much larger host), else by 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    return max(1, min(n, quota if quota is not None else 16))
+
+
 def algorithmic_bytes(level_shapes, n_kp):
     """each stage reads its inputs once and writes its outputs once (bytes per frame)."""
     px = [h * w for (h, w) in level_shapes]
@@ -486,7 +500,7 @@ def main():
         if host_fed is not None:
             out["host_fed"] = host_fed
         if gpu_last is not None:
-            nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            nthreads = host_cores()
             cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads)
             out["cpu_baseline"] = cb
             out["verified_frames"] = verified

@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -29,6 +30,7 @@ exec(open(%r).read())
 
 def run_pass(i, counters, extra):
     d = os.path.join(OUT, "sq_pass%d" % i)
+    shutil.rmtree(d, ignore_errors=True)          # a stale run directory would be picked up by the glob below
     drv = os.path.join(OUT, "sq_driver.py")
     open(drv, "w").write(DRIVER % (ROOT, extra, os.path.join(ROOT, "bench.py")))
     env = dict(os.environ, TMPDIR="/tmp")
