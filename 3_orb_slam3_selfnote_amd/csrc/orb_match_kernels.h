@@ -133,8 +133,10 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
 //   SCAN_FISHEYE  fisheye-stereo problem: image restriction per query, window-non-empty flags
 //   SCAN_FUSE     ORBmatcher::Fuse's chi-square gate on the reprojection error, ORBmatcher.cc:1585-1608
 enum { SCAN_PLAIN = 0, SCAN_UR = 1, SCAN_FISHEYE = 2, SCAN_FUSE = 3 };
+// Latency mode (few problems in flight): the candidate chunks of one problem are split over gridDim.z workgroups per query
+// block ("slices"), each writing its own sorted top-8 per query at topk + slice * slice_stride; k_topk_merge folds them.
 template <typename KT, int MODE>
-__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk) {
+__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
   __shared__ CandMeta sMeta[MATCH_CH];
@@ -186,7 +188,9 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       t = hi;
     }
   };
-  for (int base = 0; base < n; base += MATCH_CH) {
+  const int nchunks = (n + MATCH_CH - 1) / MATCH_CH;
+  const int chunk0 = (int)(((long long)nchunks * blockIdx.z) / gridDim.z), chunk1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / gridDim.z);
+  for (int base = chunk0 * MATCH_CH; base < min(n, chunk1 * MATCH_CH); base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
     __syncthreads();
     if (tid < 2 * m) sDesc[tid] = desc[(size_t)base * 2 + tid];
@@ -260,11 +264,45 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   }
   insert(pend);
   if (q < nq) {
-    K *o = topk + (qo + q) * MATCH_TOPK;
+    K *o = topk + (size_t)blockIdx.z * slice_stride + (qo + q) * MATCH_TOPK;
 #pragma unroll
     for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];
-    if (STEREO && wantAny) M.qany[qo + q] = any ? 1 : 0;
+    if (STEREO && wantAny) {
+      if (gridDim.z == 1) M.qany[qo + q] = any ? 1 : 0;
+      else if (any) M.qany[qo + q] = 1;      // sliced: the flags were zeroed before the launch; every writer stores 1
+    }
   }
+}
+
+// Folds the per-slice sorted top-8 lists of every query into slice 0's list (the S * 8 smallest keys' first 8, sorted).
+template <typename KT>
+__global__ __launch_bounds__(MATCH_NT) void k_topk_merge(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int nslices) {
+  typedef typename KT::T K;
+  const int p = blockIdx.y;
+  const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  const int q = blockIdx.x * MATCH_NT + threadIdx.x;
+  if (q >= nq) return;
+  K *o = topk + ((size_t)p * M.query_stride + q) * MATCH_TOPK;
+  K top[MATCH_TOPK];
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) top[j] = o[j];
+  for (int sl = 1; sl < nslices; sl++) {
+    const K *in = o + (size_t)sl * slice_stride;
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) {
+      K t = in[j];
+      if (t >= top[MATCH_TOPK - 1]) break;          // the slice's list is sorted: nothing further can enter
+#pragma unroll
+      for (int k = 0; k < MATCH_TOPK; k++) {
+        const K lo = t < top[k] ? t : top[k];
+        const K hi = t < top[k] ? top[k] : t;
+        top[k] = lo;
+        t = hi;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];
 }
 
 // Accept rule shared by both paths (ORBmatcher.cc:124-130 resp. :2159-2162).

@@ -138,6 +138,7 @@ static hipError_t raise_lds_limits(int device) {
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
   if (done[device]) return hipSuccess;
   const void *fns[] = {reinterpret_cast<const void *>(&k_octree<256, true>), reinterpret_cast<const void *>(&k_octree<256, false>),
+                       reinterpret_cast<const void *>(&k_octree<1024, true>), reinterpret_cast<const void *>(&k_octree<1024, false>),
                        reinterpret_cast<const void *>(&k_resize),
                        reinterpret_cast<const void *>(&k_match_resolve<Key32, true>), reinterpret_cast<const void *>(&k_match_resolve<Key32, false>),
                        reinterpret_cast<const void *>(&k_match_resolve<Key64, true>), reinterpret_cast<const void *>(&k_match_resolve<Key64, false>)};
@@ -568,8 +569,16 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[2], s));
-  if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
-  else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  // One workgroup per (frame, level).  A batch fills the chip with 256-thread workgroups; a single frame has only nlevels of them
+  // and the longest (level 0) is the critical path of the whole call, so few-frame launches use 1024 threads per workgroup.
+  const bool wide = (long long)h->nlevels * nframes <= 32;
+  if (wide) {
+    if (h->octCellsLds) hipLaunchKernelGGL((k_octree<1024, true>), dim3(h->nlevels * nframes), dim3(1024), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+    else hipLaunchKernelGGL((k_octree<1024, false>), dim3(h->nlevels * nframes), dim3(1024), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  } else {
+    if (h->octCellsLds) hipLaunchKernelGGL((k_octree<256, true>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+    else hipLaunchKernelGGL((k_octree<256, false>), dim3(h->nlevels * nframes), dim3(256), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
+  }
   if (prof) XCHECK(h, hipEventRecord(pev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[4], s));
@@ -1163,7 +1172,13 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (maxn <= 0 || maxq <= 0) return ORBX_E_ARG;
   // scratch: TOPK keys per query (grows on demand; not on the steady-state path)
   const bool k32 = maxn <= 2048;  // Key32 holds an 11-bit keypoint index
-  const size_t need = (k32 ? sizeof(uint32_t) : sizeof(unsigned long long)) * MATCH_TOPK * ((size_t)(npairs - 1) * query_stride + maxq);
+  // Latency mode: with few problems in flight the scan's candidate loop is the critical path (one workgroup per 256 queries walks
+  // every candidate), so the candidate chunks are split over up to 8 workgroups per query block and their top-8 lists merged.
+  const int qblocks = (maxq + MATCH_NT - 1) / MATCH_NT;
+  int nslices = 1;
+  if ((long long)npairs * qblocks <= 32) nslices = std::max(1, std::min(8, (maxn + MATCH_CH - 1) / MATCH_CH));
+  const size_t slice_stride = MATCH_TOPK * ((size_t)(npairs - 1) * query_stride + maxq);   // keys per slice
+  const size_t need = (k32 ? sizeof(uint32_t) : sizeof(unsigned long long)) * slice_stride * (size_t)nslices;
   if (need > m->d_topk.bytes) {
     MCHECK(m, hipStreamSynchronize(s));
     MCHECK(m, m->d_topk.reserve(need));
@@ -1171,7 +1186,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const bool prof = m->profiling && m->ev_ok;
   hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
   if (prof) MCHECK(m, hipEventRecord(pev[0], s));
-  const dim3 sgrid((maxq + MATCH_NT - 1) / MATCH_NT, npairs);
+  const dim3 sgrid(qblocks, npairs, nslices);
+  if (nslices > 1 && M.qany) MCHECK(m, hipMemsetAsync(M.qany, 0, (size_t)(npairs - 1) * query_stride + maxq, s));
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16), partner list, octave bytes; see k_match_resolve
   const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
   const size_t big = small + sizeof(uint32_t) * (size_t)((maxn + 3) / 4) + 48 * (size_t)maxn;   // + octave bytes, records, descriptors
@@ -1181,10 +1197,11 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const dim3 rblock(64 * RESOLVE_NW);
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
-    if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);             \
-    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);  \
-    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);     \
-    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p);                 \
+    if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);             \
+    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);  \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);     \
+    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);                 \
+    if (nslices > 1) hipLaunchKernelGGL((k_topk_merge<KT>), dim3(qblocks, npairs), dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, nslices); \
     if (prof) MCHECK(m, hipEventRecord(pev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
