@@ -34,6 +34,7 @@ struct MatchProblemSet {
   // ORBmatcher::Fuse (ORBmatcher.cc:1425-1658): per-candidate chi-square gate on the reprojection error, :1585-1608
   // (k_match_scan mode SCAN_FUSE); u_right = mvuRight of the keyframe, qur = projected right coordinate
   float inv_sigma2[16];
+  int npairs, scan_qblocks;  // problems of the launch; 256-query blocks per problem (k_match_scan's 1-D, XCD-aware grid)
   long long *dbg;  // diagnostic builds (-DRESOLVE_STAMPS) only: per-problem cycle sums; never read by the product
 };
 
@@ -141,14 +142,19 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   __shared__ uint4 sDesc[MATCH_CH * 2];
   __shared__ CandMeta sMeta[MATCH_CH];
   const int tid = threadIdx.x;
-  const int p = blockIdx.y;
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs by linear index, so problem p = (b % 8) + 8 * (...) and
+  // query block qb = (b / 8) % qblocks put ALL query blocks of one problem on one XCD - its candidates are fetched into ONE L2
+  // instead of up to four (a (query block, problem) grid spread a problem's four query blocks over four XCDs: 4.5x the bytes).
+  const unsigned b = blockIdx.x, qblocks = (unsigned)M.scan_qblocks;   // launch: grid = (8 * qblocks * ceil(npairs / 8), 1, slices)
+  const int qb = (int)((b >> 3) % qblocks), p = (int)((b & 7u) + 8u * (b / (8u * qblocks)));
+  if (p >= M.npairs) return;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
-  if ((int)(blockIdx.x * MATCH_NT) >= nq) return;
+  if ((int)(qb * MATCH_NT) >= nq) return;
   const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
   const float *kp = M.kp + fo * 7;
   const uint4 *desc = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
-  const int q = blockIdx.x * MATCH_NT + tid;
+  const int q = qb * MATCH_NT + tid;
   QueryWin w;
   w.live = false;
   uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -1186,7 +1186,8 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const bool prof = m->profiling && m->ev_ok;
   hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
   if (prof) MCHECK(m, hipEventRecord(pev[0], s));
-  const dim3 sgrid(qblocks, npairs, nslices);
+  M.npairs = npairs; M.scan_qblocks = qblocks;
+  const dim3 sgrid(8 * qblocks * ((npairs + 7) / 8), 1, nslices);   // XCD-aware 1-D order, see k_match_scan
   if (nslices > 1 && M.qany) MCHECK(m, hipMemsetAsync(M.qany, 0, (size_t)(npairs - 1) * query_stride + maxq, s));
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16), partner list, octave bytes; see k_match_resolve
   const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);

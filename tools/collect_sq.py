@@ -23,7 +23,7 @@ DRIVER = r'''
 import sys
 sys.path.insert(0, %r)
 import torch
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "256", "--streams", "1", "--no-cpu-baseline"] + %r
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "256", "--streams", "1", "--batches-per-step", "4", "--groups", "2", "--no-cpu-baseline", "--no-host-fed"] + %r
 exec(open(%r).read())
 '''
 

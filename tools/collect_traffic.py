@@ -35,7 +35,7 @@ torch.cuda.synchronize()
 for _ in range(3):
     L.orbx_calibration_copy(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_size_t(a.numel()), None)
 torch.cuda.synchronize()
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "256", "--streams", "1", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "256", "--streams", "1", "--batches-per-step", "4", "--groups", "2", "--no-cpu-baseline", "--no-host-fed"]
 exec(open(%r).read())
 ''' % (ROOT, CALIB_BYTES, os.path.join(ROOT, "bench.py"))
 
