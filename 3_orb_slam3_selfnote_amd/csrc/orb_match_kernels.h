@@ -194,9 +194,42 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       t = hi;
     }
   };
+  int base = 0;   // first candidate of the chunk in LDS (the lambda below reads it)
+  auto hamming_and_park = [&](int c, bool ok, uint32_t bits) {
+    const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+    // one accumulating v_bcnt_u32_b32 per word: two independent chains of four, one add (the compiler's own
+    // choice is eight zero-based counts plus an add tree: three more vector instructions per candidate)
+    int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
+    d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
+    d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
+    d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
+    const int dist = d0 + d1;
+    const K t = ok ? KT::make(dist, cell_of(bits), base + c) : KT::NONE;
+    const bool pass = t < top[MATCH_TOPK - 1];
+    // A key below the lane's current 8th best is parked in `pend`; the sorted insertion (16 min/max) runs for the whole
+    // wavefront only when some lane would have to park a second one.  With 64 lanes nearly every candidate improves
+    // SOME lane's list, so inserting on the spot executes the network for almost every candidate; parked, it runs
+    // about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
+    const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
+    if (passMask) {
+      if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
+        insert(pend);
+        pend = KT::NONE;
+      }
+      pend = pass ? t : pend;
+    }
+  };
+  // "Open" query: the cell window is the whole 64 x 48 grid, no level filter, and the float window reaches more than one grid
+  // cell beyond the image bounds on every side, so |x - u| < r and |y - v| < r hold for every keypoint PosInGrid accepts
+  // (those lie within half a cell of the bounds).  A wavefront whose live lanes are all open skips the per-candidate tests.
+  const float cellw = 1.0f / M.inv_w, cellh = 1.0f / M.inv_h;
+  const bool open = w.live && !w.checkLevels && w.cx0 == 0 && w.cx1 == 63 && w.cy0 == 0 && w.cy1 == 47 &&
+                    w.u - w.r < M.min_x - cellw && w.u + w.r > M.min_x + 65.0f * cellw && w.v - w.r < M.min_y - cellh &&
+                    w.v + w.r > M.min_y + 49.0f * cellh;
+  const bool allOpen = MODE == SCAN_PLAIN && __builtin_amdgcn_ballot_w64(w.live && !open) == 0ull;
   const int nchunks = (n + MATCH_CH - 1) / MATCH_CH;
   const int chunk0 = (int)(((long long)nchunks * blockIdx.z) / gridDim.z), chunk1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / gridDim.z);
-  for (int base = chunk0 * MATCH_CH; base < min(n, chunk1 * MATCH_CH); base += MATCH_CH) {
+  for (base = chunk0 * MATCH_CH; base < min(n, chunk1 * MATCH_CH); base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
     __syncthreads();
     if (tid < 2 * m) sDesc[tid] = desc[(size_t)base * 2 + tid];
@@ -222,6 +255,13 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       for (int cu = 0; cu < 4; cu++) {
         const int c = c0 + cu;
         const CandMeta cm = sMeta[c];
+        if (MODE == SCAN_PLAIN && allOpen) {
+          // Every live lane's window contains the whole grid and has no level filter (BASELINE's 1000x1000 stress setting, or
+          // a relocalisation-style wide search): GetFeaturesInArea returns every in-grid keypoint, so the only test left is the
+          // candidate's own usable bit, which is the same for all lanes.
+          if ((int)(cm.bits << 7) < 0) hamming_and_park(c, true, cm.bits);
+          continue;
+        }
         // cand_passes() in sign-bit arithmetic (one compare at the end instead of a dozen compare/and chains):
         // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
         const int oct = cm.bits & 0xff;
@@ -241,30 +281,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           ok = ok && !((double)(e2 * M.inv_sigma2[oct & 15]) > lim);
         }
         // Uniform branch: a divergent region would cost the same issue slots, and the wavefront-wide votes below need all lanes.
-        if (__builtin_amdgcn_ballot_w64(ok)) {
-          const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-          // one accumulating v_bcnt_u32_b32 per word: two independent chains of four, one add (the compiler's own
-          // choice is eight zero-based counts plus an add tree: three more vector instructions per candidate)
-          int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
-          d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
-          d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
-          d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
-          const int dist = d0 + d1;
-          const K t = ok ? KT::make(dist, cell_of(cm.bits), base + c) : KT::NONE;
-          const bool pass = t < top[MATCH_TOPK - 1];
-          // A key below the lane's current 8th best is parked in `pend`; the sorted insertion (16 min/max) runs for the whole
-          // wavefront only when some lane would have to park a second one.  With 64 lanes nearly every candidate improves
-          // SOME lane's list, so inserting on the spot executes the network for almost every candidate; parked, it runs
-          // about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
-          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
-          if (passMask) {
-            if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
-              insert(pend);
-              pend = KT::NONE;
-            }
-            pend = pass ? t : pend;
-          }
-        }
+        if (__builtin_amdgcn_ballot_w64(ok)) hamming_and_park(c, ok, cm.bits);
       }
     }
   }

@@ -12,7 +12,14 @@ echo "bench tumvi done"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${T}_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof -- python3 $R/bench.py --no-cpu-baseline --no-host-fed > $R/gpurun_out/${T}_prof.log 2>&1
+# one pipeline, synchronised nowhere but at the step ends: the HIP-event stage times of the bench line and rocprofv3's dispatch
+# durations must agree here (with four streams the events also see the wait for CUs held by the other streams)
+rm -rf $R/gpurun_out/${T}_s1_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_s1_prof -- python3 $R/bench.py --streams 1 --steps 4 --warmup 1 --no-cpu-baseline --no-host-fed > $R/gpurun_out/${T}_s1_bench.json 2> $R/gpurun_out/${T}_s1_prof.log
 cd $R
+cp $(ls gpurun_out/${T}_s1_prof/*/*kernel_stats.csv | head -1) gpurun_out/${T}_s1_kernel_stats.csv
+rm -rf gpurun_out/${T}_s1_prof
+python bench.py --no-match --no-cpu-baseline --no-host-fed > gpurun_out/${T}_bench_extract_only.json 2> /dev/null
 echo "kernel trace done"
 cp $(ls gpurun_out/${T}_prof/*/*kernel_stats.csv | head -1) gpurun_out/${T}_kernel_stats.csv
 rm -rf gpurun_out/${T}_prof      # the per-dispatch trace is large; the summary is what is kept
