@@ -250,18 +250,20 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
     __syncthreads();
     if (w.live) {
       const int m4u = __builtin_amdgcn_readfirstlane(m4);
+      if (MODE == SCAN_PLAIN && allOpen) {
+        // Every live lane's window contains the whole grid and has no level filter (BASELINE's 1000x1000 stress setting, or a
+        // relocalisation-style wide search): GetFeaturesInArea returns every in-grid keypoint, so the only test left is the
+        // candidate's own usable bit, which is the same for all lanes (a scalar branch).
+        for (int c = 0; c < m4u; c++) {
+          const uint32_t bits = sMeta[c].bits;
+          if (__builtin_amdgcn_readfirstlane((int)(bits << 7)) < 0) hamming_and_park(c, true, bits);
+        }
+      } else {
       for (int c0 = 0; c0 < m4u; c0 += 4)
 #pragma unroll
       for (int cu = 0; cu < 4; cu++) {
         const int c = c0 + cu;
         const CandMeta cm = sMeta[c];
-        if (MODE == SCAN_PLAIN && allOpen) {
-          // Every live lane's window contains the whole grid and has no level filter (BASELINE's 1000x1000 stress setting, or
-          // a relocalisation-style wide search): GetFeaturesInArea returns every in-grid keypoint, so the only test left is the
-          // candidate's own usable bit, which is the same for all lanes.
-          if ((int)(cm.bits << 7) < 0) hamming_and_park(c, true, cm.bits);
-          continue;
-        }
         // cand_passes() in sign-bit arithmetic (one compare at the end instead of a dozen compare/and chains):
         // an integer term is negative iff its range test is violated; |d| - r is negative iff the window test passes.
         const int oct = cm.bits & 0xff;
@@ -281,7 +283,27 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           ok = ok && !((double)(e2 * M.inv_sigma2[oct & 15]) > lim);
         }
         // Uniform branch: a divergent region would cost the same issue slots, and the wavefront-wide votes below need all lanes.
-        if (__builtin_amdgcn_ballot_w64(ok)) hamming_and_park(c, ok, cm.bits);
+        if (__builtin_amdgcn_ballot_w64(ok)) {
+          const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
+          // one accumulating v_bcnt_u32_b32 per word: two independent chains of four, one add (the compiler's own
+          // choice is eight zero-based counts plus an add tree: three more vector instructions per candidate)
+          int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
+          d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
+          d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
+          d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
+          const int dist = d0 + d1;
+          const K t = ok ? KT::make(dist, cell_of(cm.bits), base + c) : KT::NONE;
+          const bool pass = t < top[MATCH_TOPK - 1];
+          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);   // parked insertion, see hamming_and_park
+          if (passMask) {
+            if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
+              insert(pend);
+              pend = KT::NONE;
+            }
+            pend = pass ? t : pend;
+          }
+        }
+      }
       }
     }
   }
