@@ -380,37 +380,47 @@ def main():
     host_fed = None
     if rank == 0 and world == 1 and not args.no_host_fed:
         h_img = torch.from_numpy(groups[0][0]).pin_memory()
-        nd = min(2, S)
-        stage = [torch.empty_like(d_img[0]) for _ in range(nd)]
-        cstream = [torch.cuda.Stream(device=dev) for _ in range(nd)]
+        NS = 6                                  # staging buffers: uploads run up to six batches ahead of the pipelines
+        stage = [torch.empty_like(d_img[0]) for _ in range(NS)]
+        # ONE upload stream and ONE download stream: uploads run back to back at the link's full rate (two uploads in flight would
+        # share it and put the pipelines in lockstep: upload, upload, compute, compute ...), PCIe is full duplex
+        up_stream, down_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         h_out = [dict(cnt=torch.empty((B, 2), dtype=torch.int32).pin_memory(), kps=torch.empty((B, cap, 7), dtype=torch.float32).pin_memory(),
                       desc=torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory(), moq=torch.empty((B, cap), dtype=torch.int32).pin_memory(),
-                      nm=torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(nd)]
-        done = [None] * nd
+                      nm=torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(S)]
+        stage_free, pipe_done = [None] * NS, [None] * S
+        up_events = []
 
         def fed_batch(k):
-            i = k % nd
+            j, i = k % NS, k % S
             pp = pipes[i]
-            with torch.cuda.stream(cstream[i]):
-                if done[i] is not None:
-                    cstream[i].wait_event(done[i])          # the batch that read this staging buffer (and wrote these outputs) has finished
-                stage[i].copy_(h_img, non_blocking=True)
-                up = cstream[i].record_event()
+            with torch.cuda.stream(up_stream):
+                if stage_free[j] is not None:
+                    up_stream.wait_event(stage_free[j])     # the batch that read this staging buffer in place has finished
+                u0 = torch.cuda.Event(enable_timing=True); u0.record(up_stream)
+                stage[j].copy_(h_img, non_blocking=True)
+                up = torch.cuda.Event(enable_timing=True); up.record(up_stream)
+                up_events.append((u0, up))
             pp.stream.wait_event(up)
-            pp.batch(0, images=stage[i], scene=scene_dev)
-            with torch.cuda.stream(pp.stream):
+            if pipe_done[i] is not None:
+                pp.stream.wait_event(pipe_done[i])          # the pipeline's previous outputs have been downloaded
+            pp.batch(0, images=stage[j], scene=scene_dev)
+            stage_free[j] = pp.stream.record_event()
+            with torch.cuda.stream(down_stream):
+                down_stream.wait_event(stage_free[j])
                 h_out[i]["cnt"].copy_(pp.d_cnt[1:], non_blocking=True)
                 h_out[i]["kps"].copy_(pp.d_kps[1:], non_blocking=True)
                 h_out[i]["desc"].copy_(pp.d_desc[1:], non_blocking=True)
                 if not args.no_match:
                     h_out[i]["moq"].copy_(pp.d_slot if tumvi else pp.d_moq, non_blocking=True)
                     h_out[i]["nm"].copy_(pp.d_nm, non_blocking=True)
-                done[i] = pp.stream.record_event()
+                pipe_done[i] = down_stream.record_event()
 
-        for k in range(4):
+        for k in range(2 * NS):
             fed_batch(k)
         torch.cuda.synchronize()
-        nfed = 24
+        nfed = 48
+        up_events.clear()
         t0 = time.perf_counter()
         for k in range(nfed):
             fed_batch(k)
@@ -420,10 +430,12 @@ def main():
         down_b = 8 + cap * (28 + 32) + (0 if args.no_match else cap * 4 + 4)
         ffps = nfed * B / tf
         same = bool(torch.equal(h_out[0]["cnt"], pipes[0].d_cnt[1:].cpu()))
-        host_fed = {"value": round(ffps, 2), "unit": "frames/s", "batches": nfed, "buffers_in_flight": nd,
+        up_ms = float(np.mean([a.elapsed_time(b) for a, b in up_events]))
+        host_fed = {"value": round(ffps, 2), "unit": "frames/s", "batches": nfed, "staging_buffers": NS, "pipelines": S,
                     "pcie_bytes_per_frame": {"h2d": up_b, "d2h": down_b}, "pcie_GBps": round(ffps * (up_b + down_b) / 1e9, 2),
-                    "h2d_GBps": round(ffps * up_b / 1e9, 2), "pcie_spec_GBps": PCIE_SPEC_GBS, "outputs_equal_resident_run": same,
-                    "note": "pinned host frames -> HBM on a copy stream, double-buffered against compute; counts, keypoints, descriptors, match indices back to pinned memory"}
+                    "h2d_GBps": round(ffps * up_b / 1e9, 2), "upload_ms_per_batch": round(up_ms, 3),
+                    "upload_GBps_while_copying": round(B * up_b / (up_ms * 1e-3) / 1e9, 2), "pcie_spec_GBps": PCIE_SPEC_GBS, "outputs_equal_resident_run": same,
+                    "note": "pinned host frames -> HBM on one upload stream into %d staging buffers, %d pipelines; counts, keypoints, descriptors, match indices back to pinned memory on a download stream" % (NS, S)}
 
     # ---- roofline of the dominant KERNEL (per launch).  Stage -> kernel: "pyramid" is nlevels-1 launches of k_resize.
     stage_bytes = algorithmic_bytes(level_shapes, n_kp)
