@@ -330,13 +330,6 @@ __device__ unsigned int *g_fast_stamps;  // [workgroup][8] cycle deltas, set by 
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
-// Diagnostic builds (-DFAST_STOP=n): the kernel ends after section n, so that rocprofv3's per-kernel counters of successive
-// builds give each section's instruction counts by difference (tools/fast_sections.sh).  Never defined in the product build.
-#ifdef FAST_STOP
-#define FSTOP(i) do { if (FAST_STOP == (i)) { __syncthreads(); if (threadIdx.x == 0) *cellCnt = (sList[P.iniTh & 3] + sS[P.minTh & 3] + sKept[P.lap0 & 3] + sT[P.lap1 & 3] + sWCount[P.lap0 & 3]) == 0x7fffffffu ? 1u : 0u; return; } } while (0)
-#else
-#define FSTOP(i) do {} while (0)
-#endif
 __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 #ifdef FAST_STAMPS
   long long ft0 = __builtin_readcyclecounter();
@@ -392,132 +385,128 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
   __syncthreads();
   FSTAMP(0);
-  FSTOP(0);
-  const int tmin = min(P.iniTh, P.minTh);
-  // ---- pass 1: compass pre-test at minThFAST, survivors go to a dense work list as y << 6 | x (raster order = numeric order).
-  // Threads form rows of 32 (cells up to 32 interior columns, the usual 30) or 64 lanes and step down the cell, so the
-  // per-pixel index arithmetic is one add; a linear pixel index would need a division per pixel.
-  // Wavefront w owns the CONTIGUOUS rows [w * R, (w + 1) * R), R = ceil(ch / 4): its list segment is in raster order and so
-  // is the concatenation of the four segments - every later pass can keep that order with ballots and never has to sort.
+  // The reference runs cv::FAST on the cell at iniThFAST and, only if that returns nothing, again at minThFAST
+  // (ORBextractor.cc:820-828).  The score S is threshold-free, so "FAST at threshold t with non-maximum suppression" is: S > t
+  // and S strictly above the S of the 8 neighbours (a neighbour that is no corner at t has S <= t < S and can be left at 0).
+  // The kernel follows the same order - detect at iniThFAST, and again at minThFAST when the cell stayed empty - because the
+  // compass pre-test at the higher threshold passes far fewer pixels to the 16-pixel score (synthetic EuRoC frames: 81-125 per
+  // 30x30 cell instead of 227-360 at minThFAST 7, and 2 % of the cells need the second detection).
   const int xsh = cw <= 32 ? 5 : 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction; tells the compiler so (scalar loop bounds)
   const int px = lane & ((1 << xsh) - 1), sub = lane >> xsh, rpi = 64 >> xsh;   // rows per wave-instruction: 2 or 1
   const int R = (ch + 3) >> 2;
   const int rowBeg = wave * R, rowEnd = min(rowBeg + R, ch);
   const bool xin = px < cw;
-  // Every wavefront appends to its own segment of the list (at most R rows x cw entries <= 15 x 59 <= FAST_LIST_SEG) and
-  // keeps its count in a scalar register: no atomics.
   uint16_t *myList = sList + wave * FAST_LIST_SEG;
-  int wcount = 0;
-  {
-    const uint8_t *c = &sT[(rowBeg + sub + 3) * FAST_TILE_PITCH + ox + px + 3];
-    int yv = ((rowBeg + sub) << 6) | px;
-    // validity as a sign bit: row - rowEnd is negative inside the wavefront's rows; columns outside the cell start from a value
-    // that stays positive.  The pass condition is then ONE integer compare, which is also the ballot (no select / re-compare).
-    int yr = xin ? rowBeg + sub - rowEnd : 0x40000000;
-    for (int y0 = rowBeg; y0 < rowEnd; y0 += rpi, c += rpi * FAST_TILE_PITCH, yv += rpi << 6, yr += rpi) {
-      // lanes outside the cell read LDS bytes that mean nothing (or zero past the allocation) and are masked out by yr
-#ifdef FAST_PAD   // diagnostic builds only (tools/fast_sensitivity.sh): 16 extra instructions of one class per pass-1 trip, results unused
-      {
-        int pad0 = yv, pad1 = yr;
-#if FAST_PAD == 1   // full-rate VALU
-        asm volatile("v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n"
-                     "v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
-#elif FAST_PAD == 2   // half-rate VALU
-        asm volatile("v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n"
-                     "v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
-#elif FAST_PAD == 3   // scalar ALU
-        asm volatile("s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n"
-                     "s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n" ::: "s40", "s41", "s42", "s43", "scc");
-#endif
-        asm volatile("" ::"v"(pad0), "v"(pad1));
-      }
-#endif
-      const bool pass = (fast_compass_sign(c, tmin) & yr) < 0;
-      const unsigned long long b = __builtin_amdgcn_ballot_w64(pass);
-      if (pass) myList[wcount + lane_rank(b)] = (uint16_t)yv;
-      wcount += __popcll(b);
-    }
-  }
-  if (lane == 0) sWCount[wave] = (uint32_t)wcount;
-  __syncthreads();
-  FSTAMP(1);
-  FSTOP(1);
-  // The four segments are walked as one list by all 256 threads (a wavefront walking only its own segment would need a
-  // second trip whenever that segment alone exceeds 64 entries): entry e lives in segment #(prefix sums <= e).
-  const uint4 wc = *reinterpret_cast<const uint4 *>(sWCount);
-  const int pre1 = (int)wc.x, pre2 = pre1 + (int)wc.y, pre3 = pre2 + (int)wc.z, nlist = pre3 + (int)wc.w;
-  auto entry = [&](int e) -> int {
-    const int seg = (e >= pre1) + (e >= pre2) + (e >= pre3);
-    const int start = e >= pre2 ? (e >= pre3 ? pre3 : pre2) : (e >= pre1 ? pre1 : 0);
-    return sList[seg * FAST_LIST_SEG + (e - start)];
-  };
-  // ---- pass 2: full 16-pixel score for the survivors only
-  for (int e = tid; e < nlist; e += FAST_NT) {
-    const int p = entry(e);
-    const int y = p >> 6, x = p & 63;
-    const int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3]);
-    sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
-  }
-  __syncthreads();
-  FSTAMP(2);
-  FSTOP(2);
-  // ---- pass 3 (survivors only): 3x3 strict maximum inside the cell (threshold independent) -> kept list in raster order.
-  // Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.
-  // The per-cell threshold fallback (ORBextractor.cc:825-828) is decided after NMS: the cell emits A = {kept, S > iniThFAST} if
-  // that set is not empty, else {kept, S > minThFAST}.  With minThFAST <= iniThFAST every kept entry is in the second set, so
-  // an entry needs two ranks: its position in the kept list and its rank inside A.  Both come from order-preserving
-  // compactions of the same 256-entry chunk: a ballot + lane rank inside a wavefront, the four wavefronts' counts (packed,
-  // 10 bits each) through LDS - two count buffers in turn, so one barrier per chunk.  No atomics, no sorting afterwards.
   uint32_t *sCnt2 = sWCount + 4;   // [2][4]
-  int turn = 0, nkept = 0, nA = 0;
-  for (int e0 = 0; e0 < nlist; e0 += FAST_NT) {
-    const int e = e0 + tid;
-    bool keep = false, inA = false;
-    uint32_t kv = 0;
-    if (e < nlist) {
+  int turn = 0, nkept = 0;
+  int t = P.iniTh;
+  for (int detection = 0;; detection++) {
+    // ---- pass 1: compass pre-test at t, survivors go to a dense work list as y << 6 | x (raster order = numeric order).
+    // Threads form rows of 32 (cells up to 32 interior columns, the usual 30) or 64 lanes and step down the cell, so the
+    // per-pixel index arithmetic is one add; a linear pixel index would need a division per pixel.
+    // Wavefront w owns the CONTIGUOUS rows [w * R, (w + 1) * R), R = ceil(ch / 4): its list segment is in raster order and so
+    // is the concatenation of the four segments - every later pass can keep that order with ballots and never has to sort.
+    // Every wavefront appends to its own segment of the list (at most R rows x cw entries <= 15 x 59 <= FAST_LIST_SEG) and
+    // keeps its count in a scalar register: no atomics.
+    int wcount = 0;
+    {
+      const uint8_t *c = &sT[(rowBeg + sub + 3) * FAST_TILE_PITCH + ox + px + 3];
+      int yv = ((rowBeg + sub) << 6) | px;
+      // validity as a sign bit: row - rowEnd is negative inside the wavefront's rows; columns outside the cell start from a value
+      // that stays positive.  The pass condition is then ONE integer compare, which is also the ballot (no select / re-compare).
+      int yr = xin ? rowBeg + sub - rowEnd : 0x40000000;
+      for (int y0 = rowBeg; y0 < rowEnd; y0 += rpi, c += rpi * FAST_TILE_PITCH, yv += rpi << 6, yr += rpi) {
+        // lanes outside the cell read LDS bytes that mean nothing (or zero past the allocation) and are masked out by yr
+#ifdef FAST_PAD   // diagnostic builds only (tools/fast_sensitivity.sh): 16 extra instructions of one class per pass-1 trip, results unused
+        {
+          int pad0 = yv, pad1 = yr;
+#if FAST_PAD == 1   // full-rate VALU
+          asm volatile("v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n"
+                       "v_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\nv_add_u32 %0, %0, %1\nv_add_u32 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
+#elif FAST_PAD == 2   // half-rate VALU
+          asm volatile("v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n"
+                       "v_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\nv_pk_max_i16 %0, %0, %1\nv_pk_max_i16 %1, %1, %0\n" : "+v"(pad0), "+v"(pad1));
+#elif FAST_PAD == 3   // scalar ALU
+          asm volatile("s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n"
+                       "s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n" ::: "s40", "s41", "s42", "s43", "scc");
+#endif
+          asm volatile("" ::"v"(pad0), "v"(pad1));
+        }
+#endif
+        const bool pass = (fast_compass_sign(c, t) & yr) < 0;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) myList[wcount + lane_rank(b)] = (uint16_t)yv;
+        wcount += __popcll(b);
+      }
+    }
+    if (lane == 0) sWCount[wave] = (uint32_t)wcount;
+    __syncthreads();
+    FSTAMP(1);
+    // The four segments are walked as one list by all 256 threads (a wavefront walking only its own segment would need a
+    // second trip whenever that segment alone exceeds 64 entries): entry e lives in segment #(prefix sums <= e).
+    const uint4 wc = *reinterpret_cast<const uint4 *>(sWCount);
+    const int pre1 = (int)wc.x, pre2 = pre1 + (int)wc.y, pre3 = pre2 + (int)wc.z, nlist = pre3 + (int)wc.w;
+    auto entry = [&](int e) -> int {
+      const int seg = (e >= pre1) + (e >= pre2) + (e >= pre3);
+      const int start = e >= pre2 ? (e >= pre3 ? pre3 : pre2) : (e >= pre1 ? pre1 : 0);
+      return sList[seg * FAST_LIST_SEG + (e - start)];
+    };
+    // ---- pass 2: full 16-pixel score for the survivors only (a second detection recomputes the first one's entries: same
+    // values, the plane needs no clearing in between)
+    for (int e = tid; e < nlist; e += FAST_NT) {
       const int p = entry(e);
       const int y = p >> 6, x = p & 63;
-      const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
-      const int S = s[0];
-      const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
-      const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
-      const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
-      keep = (S > tmin) & (S >= 2) & (S > m2);
-      inA = keep & (S > P.iniTh);
-      kv = (uint32_t)p | ((uint32_t)S << 12);
+      const int S = fast_score_S(&sT[(y + 3) * FAST_TILE_PITCH + ox + x + 3]);
+      sS[(y + 1) * FAST_S_PITCH + x + 1] = (uint8_t)S;
     }
-    const unsigned long long bK = __builtin_amdgcn_ballot_w64(keep), bA = __builtin_amdgcn_ballot_w64(inA);
-    uint32_t *cnt = sCnt2 + 4 * turn;
-    turn ^= 1;
-    if (lane == 0) cnt[wave] = (uint32_t)__popcll(bK) | ((uint32_t)__popcll(bA) << 10);
     __syncthreads();
-    const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt);
-    const uint32_t pre = (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);   // fields stay below 1024
-    const uint32_t tot = c4.x + c4.y + c4.z + c4.w;
-    if (keep) {                                                            // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
-      const uint32_t rankA = (uint32_t)nA + (pre >> 10) + (uint32_t)lane_rank(bA);
-      sKept[nkept + (int)(pre & 1023u) + lane_rank(bK)] = kv | (rankA << 20);
+    FSTAMP(2);
+    // ---- pass 3 (survivors only): S > t and 3x3 strict maximum inside the cell -> kept list in raster order.
+    // Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.  Order-preserving compaction of
+    // each 256-entry chunk: a ballot + lane rank inside a wavefront, the four wavefronts' counts through LDS - two count
+    // buffers in turn, so one barrier per chunk.  No atomics, no sorting afterwards.
+    for (int e0 = 0; e0 < nlist; e0 += FAST_NT) {
+      const int e = e0 + tid;
+      bool keep = false;
+      uint32_t kv = 0;
+      if (e < nlist) {
+        const int p = entry(e);
+        const int y = p >> 6, x = p & 63;
+        const uint8_t *s = &sS[(y + 1) * FAST_S_PITCH + x + 1];
+        const int S = s[0];
+        const int m0 = max(max((int)s[-FAST_S_PITCH - 1], (int)s[-FAST_S_PITCH]), (int)s[-FAST_S_PITCH + 1]);
+        const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
+        const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
+        keep = (S > t) & (S >= 2) & (S > m2);
+        kv = (uint32_t)p | ((uint32_t)S << 12);
+      }
+      const unsigned long long bK = __builtin_amdgcn_ballot_w64(keep);
+      uint32_t *cnt = sCnt2 + 4 * turn;
+      turn ^= 1;
+      if (lane == 0) cnt[wave] = (uint32_t)__popcll(bK);
+      __syncthreads();
+      const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt);
+      const uint32_t pre = (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);
+      if (keep) sKept[nkept + (int)pre + lane_rank(bK)] = kv;               // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
+      nkept += (int)(c4.x + c4.y + c4.z + c4.w);
     }
-    nkept += (int)(tot & 1023u);
-    nA += (int)(tot >> 10);
+    __syncthreads();
+    FSTAMP(3);
+    // ORBextractor.cc:825: the second detection runs only if the first returned nothing (with minThFAST >= iniThFAST it could
+    // only return a subset of nothing)
+    if (nkept > 0 || detection == 1 || P.minTh >= P.iniTh) break;
+    t = P.minTh;
   }
-  __syncthreads();
-  FSTAMP(3);
-  FSTOP(3);
   // ---- pass 4: cv::FAST emits rows ascending, x ascending = the kept list's own order: every keypoint goes to its rank.
-  const bool useA = nA > 0 && P.minTh <= P.iniTh;   // (minThFAST > iniThFAST: every kept entry already exceeds iniThFAST = tmin)
-  const int nout = useA ? nA : nkept;
   uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
-  for (int e = tid; e < nkept; e += FAST_NT) {
+  const int nout = min(nkept, (int)cellCap);
+  for (int e = tid; e < nout; e += FAST_NT) {
     const uint32_t v = sKept[e], S = (v >> 12) & 255u;
-    const uint32_t rank = useA ? (v >> 20) : (uint32_t)e;
-    if ((!useA || (int)S > P.iniTh) && rank < cellCap) {
-      const uint32_t X = baseX + (v & 63u) + 3u, Y = baseY + ((v >> 6) & 63u) + 3u;
-      slots[rank] = ((S - 1u) << 24) | (Y << 12) | X;
-    }
+    const uint32_t X = baseX + (v & 63u) + 3u, Y = baseY + ((v >> 6) & 63u) + 3u;
+    slots[e] = ((S - 1u) << 24) | (Y << 12) | X;
   }
-  if (tid == 0) *cellCnt = min((uint32_t)nout, cellCap);
+  if (tid == 0) *cellCnt = (uint32_t)nout;
   FSTAMP(7);
 }
 

@@ -119,6 +119,41 @@ def test_ini_extractor_10000(pkg, oracle):
         e2.close()
 
 
+def test_threshold_fallback_cells(pkg, oracle, frame):
+    """ORBextractor.cc:820-828: a cell is detected at iniThFAST and, only when that returns nothing, again at minThFAST.  A frame
+    whose left third keeps its contrast, whose middle third is compressed to a few grey levels (corners only below iniThFAST)
+    and whose right third is flat has cells of all three kinds; k_fast runs its second detection only for the middle ones."""
+    img = frame(1003).copy()
+    w = img.shape[1]
+    mid = img[:, w // 3:2 * w // 3].astype(np.float32)
+    img[:, w // 3:2 * w // 3] = np.clip(128.0 + (mid - 128.0) * 0.18, 0, 255).astype(np.uint8)
+    img[:, 2 * w // 3:] = 97
+    for ini, mn in [(20, 7), (20, 20), (10, 25), (40, 3)]:
+        e = pkg.ORBextractor(1000, 1.2, 8, ini, mn)
+        o = oracle.OracleExtractor(1000, 1.2, 8, ini, mn)
+        try:
+            mono, kps, desc = e(img, None, (0, 1000))
+            mono_r, kps_r, desc_r = o.extract(img, (0, 1000))
+            assert mono == mono_r
+            assert_kps_equal(kps, kps_r)
+            assert np.array_equal(desc, desc_r)
+            pyr = o.pyramid(img)
+            weak = strong = 0
+            for l in range(8):
+                c_ref = o.level_candidates(pyr[l])
+                assert np.array_equal(e.level_candidates(l), c_ref), "FAST candidates level %d (ini %d, min %d)" % (l, ini, mn)
+                # response = score - 1... a candidate of a first-detection cell has S > iniThFAST
+                weak += int((c_ref[:, 2] < ini).sum())
+                strong += int((c_ref[:, 2] >= ini).sum())
+            assert strong > 100
+            if mn < ini:
+                assert weak > 100, "the frame must hold cells that only the second detection fills"
+            else:
+                assert weak == 0
+        finally:
+            e.close()
+
+
 def test_lapping_partial(ex, oex, frame):
     img = frame(1002)
     for lap in [(300, 500), (0, 375), (376, 2000)]:
