@@ -305,17 +305,16 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
 // brighter than v+t.  Pixels that fail it at minThFAST have S <= minThFAST and can never be emitted nor suppress a
 // neighbour, so their score is left at 0 and the 16-pixel score is only evaluated for the survivors.
 __device__ __forceinline__ int fast_compass_sign(const uint8_t *c, int t) {  // negative <=> the pixel passes
-  // sign-bit arithmetic (no compare -> select chains, which cost SGPR hazards and scalar mask ops)
   constexpr int Pt = FAST_TILE_PITCH;
   const int v = c[0];
-  const int p0 = c[3 * Pt], p4 = c[3], p8 = c[-3 * Pt], p12 = c[-3];
-  const int lo = v - t, hi = v + t;
-  const int d0 = p0 - lo, d4 = p4 - lo, d8 = p8 - lo, d12 = p12 - lo;   // negative <=> darker than v - t
-  const int b0 = hi - p0, b4 = hi - p4, b8 = hi - p8, b12 = hi - p12;   // negative <=> brighter than v + t
-  // two ADJACENT compass pixels both dark: (d0&d4)|(d4&d8)|(d8&d12)|(d12&d0) = (d0|d8) & (d4|d12) on the sign bits
-  const int dd = (d0 | d8) & (d4 | d12);
-  const int bb = (b0 | b8) & (b4 | b12);
-  return dd | bb;
+  const uint16_t p0 = c[3 * Pt], p4 = c[3], p8 = c[-3 * Pt], p12 = c[-3];
+  // "two ADJACENT compass pixels both darker than v - t": (dark0 | dark8) & (dark4 | dark12), and dark_a | dark_b is
+  // min(a, b) < v - t: the whole dark test is max(min(p0, p8), min(p4, p12)) < v - t, the bright one
+  // min(max(p0, p8), max(p4, p12)) > v + t.  16-bit min / max issue at the full rate on gfx950 (the 32-bit ones at half,
+  // profiles/valu_calib.json); the two comparisons are sign bits of differences, so the caller's ballot is one compare.
+  const int D = (int)(uint16_t)max((uint16_t)min(p0, p8), (uint16_t)min(p4, p12));
+  const int B = (int)(uint16_t)min((uint16_t)max(p0, p8), (uint16_t)max(p4, p12));
+  return (D - (v - t)) | ((v + t) - B);
 }
 
 #ifndef FAST_NT
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   long long ft0 = __builtin_readcyclecounter();
 #endif
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
-  __shared__ uint8_t sS[62 * FAST_S_PITCH];
+  __shared__ __align__(16) uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[4 * FAST_LIST_SEG];
   __shared__ uint32_t sKept[900];   // strict 3x3 maxima: at most ceil(cw/2) * ceil(ch/2) <= 30 * 30
   __shared__ __align__(16) uint32_t sWCount[12];   // [0..3] pass-1 list segments, [4..11] two count buffers of the ordered compactions
@@ -382,7 +381,9 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
       sT[r * FAST_TILE_PITCH + ox + cc] = img0[mul24(r, (uint32_t)pitch) + cc];
     }
   }
-  for (int idx = tid; idx < ((ch + 2) * FAST_S_PITCH) / 4; idx += FAST_NT) reinterpret_cast<uint32_t *>(sS)[idx] = 0;
+  // score plane rows 0 .. ch+1 to zero: (ch + 2) * 64 bytes = at most 244 sixteen-byte stores, one per thread, no loop
+  static_assert(62 * FAST_S_PITCH / 16 <= FAST_NT, "one 16-byte store per thread must cover the score plane");
+  if (tid < ((ch + 2) * FAST_S_PITCH) / 16) reinterpret_cast<uint4 *>(sS)[tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   FSTAMP(0);
   // The reference runs cv::FAST on the cell at iniThFAST and, only if that returns nothing, again at minThFAST
