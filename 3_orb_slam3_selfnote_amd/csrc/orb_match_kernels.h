@@ -128,6 +128,35 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
   return ok;
 }
 
+// ---- walk or scan: see k_match_walk below
+#define GRID_CELLS (64 * 48)
+#define WALK_MAX_CELLS 256
+#define WALK_MAX_N 2048
+enum { SCAN_AUTO = 0, SCAN_DENSE = 1, SCAN_WALK = 2 };
+
+// Workgroup-wide vote (all threads of a 256-thread workgroup must call it): true <=> pair p is served by k_match_walk.
+__device__ __forceinline__ bool pair_walks(const MatchProblemSet &M, int p, int n, int nq, int force, int *sVote /* one LDS word */) {
+  if (force != SCAN_AUTO) return force == SCAN_WALK;
+  if (n > WALK_MAX_N) return false;
+  const size_t qo = (size_t)p * M.query_stride;
+  if (threadIdx.x == 0) *sVote = 0;
+  __syncthreads();
+  int big = 0;
+  for (int q = threadIdx.x; q < nq; q += MATCH_NT) {
+    const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
+    const float u = M.qu[qo + q], v = M.qv[qo + q], r = M.qr[qo + q];
+    const int cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w)), cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
+    const int cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h)), cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
+    const bool live = (fl & 1) && cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0;
+    if (live && (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > WALK_MAX_CELLS) big = 1;
+  }
+  if (__builtin_amdgcn_ballot_w64(big != 0) && (threadIdx.x & 63) == 0) *sVote = 1;
+  __syncthreads();
+  const bool walks = *sVote == 0;
+  __syncthreads();   // the caller may reuse the word
+  return walks;
+}
+
 // MODE selects what is compiled into the inner loop besides the window test:
 //   SCAN_PLAIN    nothing (monocular frames)
 //   SCAN_UR       the right-coordinate test of frames with mvuRight (rectified stereo / RGB-D), ORBmatcher.cc:93-98
@@ -137,10 +166,11 @@ enum { SCAN_PLAIN = 0, SCAN_UR = 1, SCAN_FISHEYE = 2, SCAN_FUSE = 3 };
 // Latency mode (few problems in flight): the candidate chunks of one problem are split over gridDim.z workgroups per query
 // block ("slices"), each writing its own sorted top-8 per query at topk + slice * slice_stride; k_topk_merge folds them.
 template <typename KT, int MODE>
-__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride) {
+__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int force) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
   __shared__ CandMeta sMeta[MATCH_CH];
+  __shared__ int sVote;
   const int tid = threadIdx.x;
   // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs by linear index, so problem p = (b % 8) + 8 * (...) and
   // query block qb = (b / 8) % qblocks put ALL query blocks of one problem on one XCD - its candidates are fetched into ONE L2
@@ -151,6 +181,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
   if ((int)(qb * MATCH_NT) >= nq) return;
+  if (force != SCAN_DENSE && pair_walks(M, p, n, nq, force, &sVote)) return;   // k_match_walk serves this pair
   const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
   const float *kp = M.kp + fo * 7;
   const uint4 *desc = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
@@ -319,12 +350,209 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Window walk: the candidate enumeration of Frame::GetFeaturesInArea (Frame.cc:744-813) itself instead of a scan of every keypoint.
+//
+// k_match_scan streams ALL keypoints of the frame past every query: right for BASELINE's 1000x1000 stress setting (and for
+// relocalisation-style searches) whose windows cover the frame, 100x too much work for a tracking search whose windows
+// (radius 15 * scale factor) hold a few dozen keypoints.  k_match_walk stages the frame once per workgroup in the order of
+// the reference's mGrid - cells column-major (ix * 48 + iy), i.e. a counting sort by cell built in LDS - with records,
+// descriptors and original indices alongside; then every query (one per lane) walks the columns of its cell window: a column's
+// cells iy0..iy1 are ONE contiguous range of that order.  The per-candidate tests and the key are k_match_scan's, so the
+// top-8 lists - and everything k_match_resolve derives from them - are the same whichever kernel made them (a key is unique
+// per keypoint, so the list does not depend on the order candidates are met in).
+//
+// Which kernel serves a frame pair is decided on the device, per pair, by the same rule in both kernels (and k_topk_merge):
+// the walk when no query's cell window exceeds WALK_MAX_CELLS cells and the frame has at most 2048 keypoints (Key32; 50 bytes of
+// LDS per keypoint), else the scan.  `force` (orbm_set_scan_mode, the host-pointer entry points) skips the vote.
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef WALK_STAMPS   // diagnostic builds only (tools/walk_stamps.py): cycles per phase, thread 0 of every workgroup
+#define WSTAMP(i) do { const long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && M.dbg) M.dbg[(size_t)blockIdx.x * 8 + (i)] = t_ - wt0; wt0 = t_; } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
+#define WALK_LIST 16   // passing candidates a lane collects before it computes their distances
+struct WalkRec { float x, y; uint32_t w; };   // w = octave | gx << 4 | gy << 10 | usable << 16 | keypoint index << 17
+
+template <typename KT, int MODE>
+__global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, typename KT::T *topk, int force, int capn /* LDS rows: >= every n, <= WALK_MAX_N */) {
+  typedef typename KT::T K;
+  extern __shared__ __align__(16) uint32_t smem_walk[];
+  __shared__ int sVote;
+  __shared__ uint32_t sWaveSum[MATCH_NT / 64];
+#ifdef WALK_STAMPS
+  long long wt0 = __builtin_readcyclecounter();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned b = blockIdx.x, qblocks = (unsigned)M.scan_qblocks;   // same XCD-aware order as k_match_scan
+  const int qb = (int)((b >> 3) % qblocks), p = (int)((b & 7u) + 8u * (b / (8u * qblocks)));
+  if (p >= M.npairs) return;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  if ((int)(qb * MATCH_NT) >= nq) return;
+  if (!pair_walks(M, p, n, nq, force, &sVote)) return;
+  WSTAMP(0);
+  const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
+  const float *kp = M.kp + fo * 7;
+  const uint4 *desc = reinterpret_cast<const uint4 *>(M.desc + fo * 32);
+  constexpr bool STEREO = MODE == SCAN_FISHEYE, UR = MODE == SCAN_UR, NEEDUR = MODE == SCAN_UR || MODE == SCAN_FUSE;
+  // LDS: cell starts (GRID_CELLS + 1 words, +3 pad); per keypoint IN CELL ORDER a 12-byte record (+ its right coordinate for the
+  // modes that test it); per lane a short list of passing candidates.  Descriptors stay in global memory: only the few
+  // candidates that pass every test are compared, and 32 more bytes per keypoint would halve the workgroups per CU.
+  uint32_t *sCell = smem_walk;
+  WalkRec *sRec = reinterpret_cast<WalkRec *>(smem_walk + GRID_CELLS + 4);
+  float *sUr = reinterpret_cast<float *>(sRec + capn);
+  uint16_t *sList = reinterpret_cast<uint16_t *>(sUr + (NEEDUR ? capn : 0));   // [WALK_LIST][MATCH_NT]
+  for (int c = tid; c < GRID_CELLS + 4; c += MATCH_NT) sCell[c] = 0u;
+  __syncthreads();
+  // ---- counting sort by cell: histogram (the atomic's return value is the keypoint's rank inside its cell) ...
+  constexpr int PER = WALK_MAX_N / MATCH_NT;   // keypoints per thread
+  float kx[PER], ky[PER], kur[PER];
+  uint32_t kbits[PER], krank[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int i = tid + j * MATCH_NT;
+    kbits[j] = 0u; krank[j] = 0u; kx[j] = 0.f; ky[j] = 0.f; kur[j] = -1.f;
+    if (i < n) {
+      kx[j] = kp[(size_t)i * 7];
+      ky[j] = kp[(size_t)i * 7 + 1];
+      const int oct = __float_as_int(kp[(size_t)i * 7 + 5]);
+      if (NEEDUR) kur[j] = M.u_right ? M.u_right[fo + i] : -1.f;
+      const bool claimed = M.slot[fo + i] >= 0 && M.slot_obs[fo + i];
+      kbits[j] = cand_bits(kx[j], ky[j], oct, claimed, M);
+      if ((kbits[j] >> 25) & 1u) krank[j] = atomicAdd(&sCell[cell_of(kbits[j])], 1u);
+    }
+  }
+  __syncthreads();
+  WSTAMP(1);
+  // ---- ... exclusive prefix sums over the 3072 cells (12 consecutive cells per thread) ...
+  {
+    constexpr int CPT = GRID_CELLS / MATCH_NT;
+    uint32_t loc[CPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) { loc[j] = sCell[tid * CPT + j]; sum += loc[j]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) sWaveSum[wid] = inc;
+    __syncthreads();
+    uint32_t off = inc - sum;
+    for (int w2 = 0; w2 < wid; w2++) off += sWaveSum[w2];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) { sCell[tid * CPT + j] = off; off += loc[j]; }
+    if (tid == MATCH_NT - 1) sCell[GRID_CELLS] = off;
+  }
+  __syncthreads();
+  WSTAMP(2);
+  // ---- ... scatter the records to start[cell] + rank
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int i = tid + j * MATCH_NT;
+    if (i < n && ((kbits[j] >> 25) & 1u)) {
+      const uint32_t pos = sCell[cell_of(kbits[j])] + krank[j];
+      const uint32_t wv = (kbits[j] & 0xfu) | (((kbits[j] >> 8) & 0x3fu) << 4) | (((kbits[j] >> 16) & 0x3fu) << 10) | (((kbits[j] >> 24) & 1u) << 16) | ((uint32_t)i << 17);
+      sRec[pos] = WalkRec{kx[j], ky[j], wv};
+      if (NEEDUR) sUr[pos] = kur[j];
+    }
+  }
+  __syncthreads();
+  WSTAMP(3);
+  // ---- every query walks its window
+  const int q = qb * MATCH_NT + tid;
+  if (q >= nq) return;
+  const QueryWin w = load_query(M, qo, q);
+  const int nleft = STEREO && M.qside ? M.nleft : n;
+  const bool sideR = STEREO && M.qside && M.qside[qo + q] != 0;
+  const bool wantAny = STEREO && M.qany != nullptr;
+  bool any = false;
+  K top[MATCH_TOPK];
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
+  if (w.live) {
+    const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
+    const uint4 qa = qp[0], qb4 = qp[1];
+    uint16_t *myList = sList + tid;
+    // One flat loop over the window's candidates (column after column; the cells iy0..iy1 of a column are one range of the cell
+    // order): lanes advance independently, so a wavefront runs as long as its busiest lane, not as the sum over columns of the
+    // busiest lane per column.  Candidates that pass every test are only noted; their descriptors are fetched and compared
+    // WALK_LIST at a time - the Hamming distance and the top-8 insertion run for the few that pass, not once per visited cell entry.
+    int ix = w.cx0, j = (int)sCell[ix * 48 + w.cy0], j1 = (int)sCell[ix * 48 + w.cy1 + 1], cnt = 0;
+    bool more = w.cx0 <= w.cx1;   // (a NaN or negative radius gives an empty column range: no candidates, as in the reference's loops)
+    for (;;) {
+      if (more) {
+        if (j >= j1) {
+          if (++ix > w.cx1) more = false;
+          else { j = (int)sCell[ix * 48 + w.cy0]; j1 = (int)sCell[ix * 48 + w.cy1 + 1]; }
+        } else {
+          const WalkRec rec = sRec[j];
+          const int oct = rec.w & 0xf, i = (int)(rec.w >> 17);
+          // GetFeaturesInArea's own tests (level range, |dx| < r, |dy| < r; the cell window is the loop itself), Frame.cc:794-806
+          bool in = fabsf(rec.x - w.u) < w.r && fabsf(rec.y - w.v) < w.r;
+          if (w.checkLevels) in = in && oct >= w.minl && (w.maxl < 0 || oct <= w.maxl);
+          if (STEREO) in = in && ((i >= nleft) == sideR);
+          if (STEREO && wantAny) any = any || in;
+          bool ok = in && ((rec.w >> 16) & 1u);                                  // not held by a map point with observations
+          if (NEEDUR) {
+            const float cur = sUr[j];
+            if (UR) ok = ok && !(cur > 0.f && fabsf(w.ur - cur) > w.r);          // ORBmatcher.cc:93-98, :2139-2146
+            if (MODE == SCAN_FUSE) {                                             // ORBmatcher.cc:1585-1608
+              const float ex = w.u - rec.x, ey = w.v - rec.y;
+              float e2 = ex * ex + ey * ey;
+              double lim = 5.99;
+              if (cur >= 0.f) { const float er = w.ur - cur; e2 = e2 + er * er; lim = 7.8; }
+              ok = ok && !((double)(e2 * M.inv_sigma2[oct & 15]) > lim);
+            }
+          }
+          if (ok) { myList[cnt * MATCH_NT] = (uint16_t)j; cnt++; }
+          j++;
+        }
+      }
+      // The lists are emptied by the whole wavefront at once - when some lane's list is full, and when every lane is through -
+      // so that the descriptor fetches of all lanes overlap (lane-by-lane flushes would each wait out their own memory latency).
+      const bool anyMore = __builtin_amdgcn_ballot_w64(more) != 0ull;
+      if (__builtin_amdgcn_ballot_w64(cnt == WALK_LIST) != 0ull || !anyMore) {
+        for (int e = 0; __builtin_amdgcn_ballot_w64(e < cnt) != 0ull; e++) {
+          if (e < cnt) {
+            const uint32_t wv = sRec[myList[e * MATCH_NT]].w;
+            const int i = (int)(wv >> 17);
+            const uint4 a = desc[(size_t)i * 2], b2 = desc[(size_t)i * 2 + 1];
+            const int dist = __popc(a.x ^ qa.x) + __popc(a.y ^ qa.y) + __popc(a.z ^ qa.z) + __popc(a.w ^ qa.w) + __popc(b2.x ^ qb4.x) +
+                             __popc(b2.y ^ qb4.y) + __popc(b2.z ^ qb4.z) + __popc(b2.w ^ qb4.w);
+            K t = KT::make(dist, ((wv >> 4) & 0x3fu) * 48u + ((wv >> 10) & 0x3fu), i);
+            if (t < top[MATCH_TOPK - 1]) {
+#pragma unroll
+              for (int k2 = 0; k2 < MATCH_TOPK; k2++) {
+                const K lo = t < top[k2] ? t : top[k2];
+                const K hi = t < top[k2] ? top[k2] : t;
+                top[k2] = lo;
+                t = hi;
+              }
+            }
+          }
+        }
+        cnt = 0;
+      }
+      if (!anyMore) break;
+    }
+  }
+  WSTAMP(4);
+  K *o = topk + (qo + q) * MATCH_TOPK;
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];
+  if (STEREO && wantAny) M.qany[qo + q] = any ? 1 : 0;
+  WSTAMP(5);
+}
+
 // Folds the per-slice sorted top-8 lists of every query into slice 0's list (the S * 8 smallest keys' first 8, sorted).
 template <typename KT>
-__global__ __launch_bounds__(MATCH_NT) void k_topk_merge(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int nslices) {
+__global__ __launch_bounds__(MATCH_NT) void k_topk_merge(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int nslices, int force) {
   typedef typename KT::T K;
+  __shared__ int sVote;
   const int p = blockIdx.y;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  if ((int)(blockIdx.x * MATCH_NT) >= nq) return;
+  if (force != SCAN_DENSE && pair_walks(M, p, n, nq, force, &sVote)) return;   // the walk wrote one list per query: nothing to fold
   const int q = blockIdx.x * MATCH_NT + threadIdx.x;
   if (q >= nq) return;
   K *o = topk + ((size_t)p * M.query_stride + q) * MATCH_TOPK;

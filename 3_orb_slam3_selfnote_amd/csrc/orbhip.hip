@@ -137,7 +137,9 @@ static hipError_t raise_lds_limits(int device) {
   std::lock_guard<std::mutex> lock(mu);
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
   if (done[device]) return hipSuccess;
-  const void *fns[] = {reinterpret_cast<const void *>(&k_octree<256, true>), reinterpret_cast<const void *>(&k_octree<256, false>),
+  const void *fns[] = {reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_PLAIN>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_UR>),
+                       reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FISHEYE>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FUSE>),
+                       reinterpret_cast<const void *>(&k_octree<256, true>), reinterpret_cast<const void *>(&k_octree<256, false>),
                        reinterpret_cast<const void *>(&k_octree<1024, true>), reinterpret_cast<const void *>(&k_octree<1024, false>),
                        reinterpret_cast<const void *>(&k_resize),
                        reinterpret_cast<const void *>(&k_match_resolve<Key32, true>), reinterpret_cast<const void *>(&k_match_resolve<Key32, false>),
@@ -943,6 +945,8 @@ struct orbm_handle {
   DevBuf d_partner, d_qside, d_qany;
   DevBuf d_lfq;       // query arrays written by k_lastframe_project (orbm_search_by_projection_last_frame_batch_device)
   DevBuf d_block;     // inputs + outputs of one host-pointer search, one block (see search_host)
+  int scan_mode = 0;  // SCAN_AUTO / SCAN_DENSE / SCAN_WALK of the projection searches (orbm_set_scan_mode); next_scan_mode: one search only
+  int next_scan_mode = -1;
   void *pin = nullptr; size_t pin_bytes = 0;   // its pinned host mirror
   DevBuf scratch[8];  // grow-only buffers of the per-node / per-map-point entry points (SearchByBoW, ...)
   // fisheye-stereo options of the NEXT projection search (set by the *_fisheye entry points, consumed and cleared by
@@ -964,7 +968,7 @@ struct orbm_handle {
     }                                                                                         \
   } while (0)
 
-#ifdef RESOLVE_STAMPS
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS)
 static void *getenv_ptr(const char *name) { const char *e = getenv(name); return e ? (void *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
 
@@ -1010,6 +1014,14 @@ void orbm_set_profiling(orbm_t *m, int enable) {
       for (auto &e : set) ok = ok && hipEventCreate(&e) == hipSuccess;
     m->ev_ok = ok;
   }
+}
+
+// 0 = decided per frame pair on the device (default), 1 = always k_match_scan, 2 = always k_match_walk (frames of at most 2048
+// keypoints; larger ones are scanned whatever the mode).  Results do not depend on the mode.
+int orbm_set_scan_mode(orbm_t *m, int mode) {
+  if (!m || mode < SCAN_AUTO || mode > SCAN_WALK) return ORBX_E_ARG;
+  m->scan_mode = mode;
+  return 0;
 }
 
 float orbm_get_last_ms(orbm_t *m) {
@@ -1157,7 +1169,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
-#ifdef RESOLVE_STAMPS
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS)
   M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
 #endif
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
@@ -1196,13 +1208,26 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const size_t lds = ldscand ? big : small;
   if (lds > 160 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
   const dim3 rblock(64 * RESOLVE_NW);
+  // Window walk (k_match_walk) or full scan (k_match_scan): decided per pair on the device unless a mode is forced; frames beyond
+  // 2048 keypoints (Key64) are always scanned.  The walk's workgroups come first: they are the short ones.
+  const int force = !k32 ? SCAN_DENSE : (m->next_scan_mode >= 0 ? m->next_scan_mode : m->scan_mode);
+  m->next_scan_mode = -1;
+  const int capn = std::min((maxn + 7) & ~7, WALK_MAX_N);
+  const size_t wlds = sizeof(uint32_t) * (GRID_CELLS + 4) + (12 + (fuse || M.u_right ? 4 : 0)) * (size_t)capn + 2 * WALK_LIST * MATCH_NT;
+  const dim3 wgrid(8 * qblocks * ((npairs + 7) / 8));
+#define LAUNCH_WALK(MODE) hipLaunchKernelGGL((k_match_walk<Key32, MODE>), wgrid, dim3(MATCH_NT), wlds, s, M, (Key32::T *)m->d_topk.p, force, capn)
+  if (force != SCAN_DENSE) {
+    if (fuse) LAUNCH_WALK(SCAN_FUSE); else if (M.qside) LAUNCH_WALK(SCAN_FISHEYE); else if (M.u_right) LAUNCH_WALK(SCAN_UR); else LAUNCH_WALK(SCAN_PLAIN);
+  }
+#undef LAUNCH_WALK
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
-    if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);             \
-    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);  \
-    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);     \
-    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride);                 \
-    if (nslices > 1) hipLaunchKernelGGL((k_topk_merge<KT>), dim3(qblocks, npairs), dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, nslices); \
+    if (force == SCAN_WALK) {}                                                                                            \
+    else if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);             \
+    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);  \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);     \
+    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);                 \
+    if (nslices > 1 && force != SCAN_WALK) hipLaunchKernelGGL((k_topk_merge<KT>), dim3(qblocks, npairs), dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, nslices, force); \
     if (prof) MCHECK(m, hipEventRecord(pev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
@@ -1295,6 +1320,19 @@ static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q
   dq.min_level = (const int32_t *)(dp + pMinl.off);
   dq.max_level = (const int32_t *)(dp + pMaxl.off);
   dq.flags = q->flags ? (const uint8_t *)(dp + pFl.off) : nullptr;
+  // The radii are on the host here: the walk-or-scan decision (pair_walks) is taken now and only the chosen kernels are launched.
+  if (m->scan_mode == SCAN_AUTO) {
+    const float iw = (float)ORBM_GRID_COLS / (f->max_x - f->min_x), ih = (float)ORBM_GRID_ROWS / (f->max_y - f->min_y);
+    bool big = n > WALK_MAX_N;
+    for (int i = 0; i < nq && !big; i++) {
+      if (q->flags && !(q->flags[i] & 1)) continue;
+      const float u = q->u[i], v = q->v[i], r = q->radius[i];
+      const int cx0 = std::max(0, (int)floorf((u - f->min_x - r) * iw)), cx1 = std::min(63, (int)ceilf((u - f->min_x + r) * iw));
+      const int cy0 = std::max(0, (int)floorf((v - f->min_y - r) * ih)), cy1 = std::min(47, (int)ceilf((v - f->min_y + r) * ih));
+      if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0 && (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > WALK_MAX_CELLS) big = true;
+    }
+    m->next_scan_mode = big ? SCAN_DENSE : SCAN_WALK;
+  }
   int rc = orbm_search_by_projection_batch_device(m, &df, n, nullptr, 0, &dq, nq, nullptr, 0, 1, nnratio, th_dist, use_second,
                                                   (int32_t *)(dp + pSlot.off), dp + pSobs.off, (int32_t *)(dp + pMoq.off),
                                                   (int32_t *)(dp + pBd.off), (int32_t *)(dp + pNm.off), s);

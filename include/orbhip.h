@@ -476,11 +476,22 @@ void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K
 void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *min_x, float *max_x, float *min_y,
                        float *max_y);
 
+/* How the projection searches enumerate a query's candidates.  The reference walks the grid cells of the query's window
+ * (Frame::GetFeaturesInArea, Frame.cc:744-813); on the device that is k_match_walk, right for tracking-sized windows, while
+ * k_match_scan streams every keypoint of the frame past every query, right when the windows cover the frame (BASELINE's
+ * 1000x1000 setting, relocalisation).  ORBM_SCAN_AUTO (default) decides per frame pair on the device: the walk when no
+ * query's window exceeds 256 grid cells and the frame has at most 2048 keypoints, else the scan.  The two produce the same
+ * candidate lists, so results never depend on the mode; it exists for tests and measurements.  Returns 0 or ORBX_E_ARG. */
+#define ORBM_SCAN_AUTO 0
+#define ORBM_SCAN_DENSE 1
+#define ORBM_SCAN_WALK 2
+int orbm_set_scan_mode(orbm_t *m, int mode);
+
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */
 void orbm_set_profiling(orbm_t *m, int enable);
 float orbm_get_last_ms(orbm_t *m);
 /* Per-kernel split, averaged over the searches launched since orbm_set_profiling(m, 1) (ring of 32 event sets, as for
- * orbx_get_stage_ms): ms[0] = k_match_scan, ms[1] = k_match_resolve.  Returns 2, or 0 if unavailable. */
+ * orbx_get_stage_ms): ms[0] = k_match_walk + k_match_scan (+ k_topk_merge), ms[1] = k_match_resolve.  Returns 2, or 0 if unavailable. */
 int orbm_get_stage_ms(orbm_t *m, float *ms, int cap);
 
 #ifdef __cplusplus

@@ -23,9 +23,13 @@ def both_frames(pkg, oracle, k1, d1, sf, bounds=(0.0, 752.0, 0.0, 480.0)):
     return F, OF
 
 
-@pytest.fixture(scope="module")
-def matcher(pkg):
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["auto", "scan", "walk"])
+def matcher(pkg, request):
+    """Every projection-search test runs three times: candidate enumeration decided on the device (default), forced to the
+    all-keypoints scan (k_match_scan) and forced to the grid-window walk (k_match_walk, Frame::GetFeaturesInArea's own order).
+    The oracle's answer is the same for all three."""
     m = pkg.ORBmatcher(0.8, True)
+    m.set_scan_mode(request.param)
     yield m
     m.close()
 
