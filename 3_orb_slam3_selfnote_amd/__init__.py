@@ -29,7 +29,7 @@ E_EMPTY, E_ARG, E_HIP, E_CAP = -1, -2, -3, -4
 ABI_SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
-    "orbx_extract_batch_device", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
+    "orbx_extract_batch_device", "orbx_get_host_us", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
@@ -97,6 +97,7 @@ def load(build_if_needed=True):
     L.orbx_max_keypoints.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, vp, i32, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, sz, sz, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.orbx_get_host_us.argtypes = [vp, vp, i32]
     L.orbx_level_info.argtypes = [vp, i32, vp, vp]
     L.orbx_download_level.argtypes = [vp, i32, i32, i32, vp, sz]
     L.orbx_download_blurred_level.argtypes = [vp, i32, i32, vp, sz]

@@ -1025,15 +1025,18 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
 #pragma unroll
   for (int l = 1; l < ORB_MAXL; l++)
     if (l < P.nlevels && j >= P.geom[l].kpBase) level = l;
-  int nTot = 0, lapBefore = 0, monoBefore = 0, myCount = 0;
+  int nTot = 0, lapTot = 0, lapBefore = 0, monoBefore = 0, myCount = 0;
 #pragma unroll
   for (int l = 0; l < ORB_MAXL; l++)
     if (l < P.nlevels) {
       const int c = lc[l * 2], lp = lc[l * 2 + 1];
       nTot += c;
+      lapTot += lp;
       if (l < level) { lapBefore += lp; monoBefore += c - lp; }
       if (l == level) myCount = c;
     }
+  // the frame's totals (keypoints, monoIndex of operator(): ORBextractor.cc:1169-1182) are written by its first wavefront
+  if (j == 0 && lane == 0) { P.out_counts[frame * 2] = nTot; P.out_counts[frame * 2 + 1] = nTot - lapTot; }
   const LevelGeom G = P.geom[level];
   const int i = j - G.kpBase;
   if (i >= myCount) return;
@@ -1142,9 +1145,6 @@ __global__ __launch_bounds__(256) void k_describe(FrameParams P) {
       k.class_id = -1;
       reinterpret_cast<KpOut *>(P.out_kps)[(size_t)frame * P.cap + dst] = k;
     }
-  }
-  if (i == 0 && level == 0 && lane == 0) {
-    // never reached when level 0 is empty; counts are written by k_counts instead
   }
 }
 
@@ -1281,15 +1281,4 @@ __global__ __launch_bounds__(256) void k_remap_linear(const uint8_t *src, int sr
   const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
   const int acc = tap(iy, ix) * w00 + tap(iy, ix + 1) * w01 + tap(iy + 1, ix) * w10 + tap(iy + 1, ix + 1) * w11;
   dst[(size_t)y * dstride + x] = (uint8_t)((acc + (1 << 14)) >> 15);
-}
-
-// per-frame {n, monoIndex} (ORBextractor.cc:1183 returns monoIndex)
-__global__ void k_counts(FrameParams P) {
-  const int frame = blockIdx.x * blockDim.x + threadIdx.x;
-  if (frame >= P.nframes) return;
-  const int32_t *lc = P.lcnt + (size_t)frame * P.nlevels * 2;
-  int n = 0, lap = 0;
-  for (int l = 0; l < P.nlevels; l++) { n += lc[l * 2]; lap += lc[l * 2 + 1]; }
-  P.out_counts[frame * 2] = n;
-  P.out_counts[frame * 2 + 1] = n - lap;
 }

@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <chrono>
 
 #include "../../include/orbhip.h"
 #include "orb_kernels.h"
@@ -75,8 +76,9 @@ struct orbx_handle {
   // device memory
   DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_tiles, d_xtab,
       d_ytab, d_disc;
-  DevBuf d_img, d_okps, d_odesc, d_ocounts;  // staging for the host entry point
+  DevBuf d_img, d_okps;  // staging for the host entry point (d_okps: counts + keypoints + descriptors, one block)
   hipStream_t stream = nullptr;
+  float host_us[4] = {0, 0, 0, 0};          // orbx_extract's last call: staging copy, submission, wait, copy-out (orbx_get_host_us)
   // last call
   FrameParams last{};
   bool have_last = false;
@@ -92,7 +94,7 @@ struct orbx_handle {
   // the per-frame sequence of orbx_extract (H2D, 12 launches, 3 D2H) captured once per configuration as a hipGraph:
   // one submission per frame instead of 16
   hipGraphExec_t graph = nullptr;
-  struct { int rows = 0, cols = 0, lap0 = 0, lap1 = 0, icap = 0; const void *pin_in = nullptr, *pin_out = nullptr, *d_img = nullptr, *d_okps = nullptr, *d_odesc = nullptr, *d_pyr = nullptr; } graph_key;
+  struct { int rows = 0, cols = 0, lap0 = 0, lap1 = 0, icap = 0; const void *pin_in = nullptr, *pin_out = nullptr, *d_img = nullptr, *d_okps = nullptr, *d_pyr = nullptr; } graph_key;
   bool graph_ok = true;   // cleared (for good) if capture / instantiation fails: the plain path is used instead
   // profiling
   bool profiling = false;
@@ -244,7 +246,7 @@ void orbx_destroy(orbx_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
-                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps, &h->d_odesc, &h->d_ocounts};
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps};
   for (DevBuf *b : bufs) b->release();
   for (DevBuf &b : h->stereo) b.release();
   for (DevBuf &b : h->maps) b.release();
@@ -584,8 +586,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(pev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[4], s));
-  hipLaunchKernelGGL(k_describe, dim3(((h->totalKp + 3) / 4) * nframes), dim3(256), 0, s, P);
-  hipLaunchKernelGGL(k_counts, dim3((nframes + 63) / 64), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(k_describe, dim3(((h->totalKp + 3) / 4) * nframes), dim3(256), 0, s, P);   // also writes the frame totals
   if (prof) { XCHECK(h, hipEventRecord(pev[5], s)); h->prof_head++; h->stage_valid = true; }
   XCHECK(h, hipGetLastError());
   h->last = P;
@@ -611,12 +612,11 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
   const size_t dstride = align_up((size_t)cols, 64);
   XCHECK(h, hipSetDevice(h->device));
   XCHECK(h, h->d_img.reserve(dstride * rows));
-  XCHECK(h, h->d_okps.reserve(sizeof(orbx_keypoint_t) * (size_t)icap));
-  XCHECK(h, h->d_odesc.reserve(32 * (size_t)icap));
-  XCHECK(h, h->d_ocounts.reserve(sizeof(int32_t) * 2));
-  // pinned staging: one H2D, all kernels, three D2H and ONE synchronisation per frame
+  // pinned staging: one H2D, all kernels, one D2H (counts, keypoints and descriptors are one device block) and ONE synchronisation
+  // per frame
   const size_t in_bytes = dstride * rows, kp_bytes = sizeof(orbx_keypoint_t) * (size_t)icap, de_bytes = 32 * (size_t)icap;
-  const size_t out_bytes = 16 + kp_bytes + de_bytes;
+  const size_t kp_off = 64, de_off = kp_off + align_up(kp_bytes, 64), out_bytes = de_off + de_bytes;   // [counts][keypoints][descriptors], 64-byte aligned parts
+  XCHECK(h, h->d_okps.reserve(out_bytes));
   if (h->pin_in_bytes < in_bytes) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     h->pin_in = nullptr; h->pin_in_bytes = 0;
@@ -629,23 +629,24 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
     XCHECK(h, hipHostMalloc(&h->pin_out, out_bytes, hipHostMallocDefault));
     h->pin_out_bytes = out_bytes;
   }
+  const auto t0 = std::chrono::steady_clock::now();
   for (int y = 0; y < rows; y++) memcpy((uint8_t *)h->pin_in + (size_t)y * dstride, image + (size_t)y * stride, (size_t)cols);
+  const auto t1 = std::chrono::steady_clock::now();
   uint8_t *po = (uint8_t *)h->pin_out;
   auto enqueue = [&]() -> int {  // the whole per-frame sequence on h->stream
     XCHECK(h, hipMemcpyAsync(h->d_img.p, h->pin_in, in_bytes, hipMemcpyHostToDevice, h->stream));
+    uint8_t *dout = (uint8_t *)h->d_okps.p;
     const int r = orbx_extract_batch_device(h, (const uint8_t *)h->d_img.p, rows, cols, dstride, dstride * rows, 1, lap0, lap1,
-                                            (orbx_keypoint_t *)h->d_okps.p, (uint8_t *)h->d_odesc.p, (int32_t *)h->d_ocounts.p, icap, h->stream);
+                                            (orbx_keypoint_t *)(dout + kp_off), dout + de_off, (int32_t *)dout, icap, h->stream);
     if (r < 0) return r;
-    XCHECK(h, hipMemcpyAsync(po, h->d_ocounts.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, h->stream));
-    XCHECK(h, hipMemcpyAsync(po + 16, h->d_okps.p, kp_bytes, hipMemcpyDeviceToHost, h->stream));
-    XCHECK(h, hipMemcpyAsync(po + 16 + kp_bytes, h->d_odesc.p, de_bytes, hipMemcpyDeviceToHost, h->stream));
+    XCHECK(h, hipMemcpyAsync(po, dout, out_bytes, hipMemcpyDeviceToHost, h->stream));
     return 0;
   };
   bool launched = false;
   if (h->graph_ok && !h->profiling) {
     auto &K = h->graph_key;
     const bool same = h->graph && K.rows == rows && K.cols == cols && K.lap0 == lap0 && K.lap1 == lap1 && K.icap == icap && K.pin_in == h->pin_in &&
-                      K.pin_out == h->pin_out && K.d_img == h->d_img.p && K.d_okps == h->d_okps.p && K.d_odesc == h->d_odesc.p && K.d_pyr == h->d_pyr.p;
+                      K.pin_out == h->pin_out && K.d_img == h->d_img.p && K.d_okps == h->d_okps.p && K.d_pyr == h->d_pyr.p;
     if (!same) {
       if (h->graph) { (void)hipGraphExecDestroy(h->graph); h->graph = nullptr; }
       hipGraph_t g = nullptr;
@@ -656,7 +657,7 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
         const hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (r == 0 && e == hipSuccess && g && hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0) == hipSuccess) {
           K.rows = rows; K.cols = cols; K.lap0 = lap0; K.lap1 = lap1; K.icap = icap; K.pin_in = h->pin_in; K.pin_out = h->pin_out;
-          K.d_img = h->d_img.p; K.d_okps = h->d_okps.p; K.d_odesc = h->d_odesc.p; K.d_pyr = h->d_pyr.p;
+          K.d_img = h->d_img.p; K.d_okps = h->d_okps.p; K.d_pyr = h->d_pyr.p;
         } else {
           h->graph = nullptr;
           h->graph_ok = false;
@@ -674,7 +675,9 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
     }
   }
   if (!launched) { rc = enqueue(); if (rc < 0) return rc; }
+  const auto t2 = std::chrono::steady_clock::now();
   XCHECK(h, hipStreamSynchronize(h->stream));
+  const auto t3 = std::chrono::steady_clock::now();
   h->last_pending = false;   // this entry point returns with the frame's work complete
   int32_t counts[2];
   memcpy(counts, po, sizeof(counts));
@@ -682,10 +685,21 @@ int orbx_extract(orbx_t *h, const uint8_t *image, int rows, int cols, size_t str
   if (counts[0] > cap) return ORBX_E_CAP;
   if (counts[0] > 0) {
     if (!keypoints || !descriptors) return ORBX_E_ARG;
-    memcpy(keypoints, po + 16, sizeof(orbx_keypoint_t) * (size_t)counts[0]);
-    memcpy(descriptors, po + 16 + kp_bytes, 32 * (size_t)counts[0]);
+    memcpy(keypoints, po + kp_off, sizeof(orbx_keypoint_t) * (size_t)counts[0]);
+    memcpy(descriptors, po + de_off, 32 * (size_t)counts[0]);
   }
+  const auto t4 = std::chrono::steady_clock::now();
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
+  h->host_us[0] = us(t0, t1); h->host_us[1] = us(t1, t2); h->host_us[2] = us(t2, t3); h->host_us[3] = us(t3, t4);
   return counts[1];
+}
+
+// Host-side split of the last orbx_extract call, microseconds: copy of the image into pinned staging, submission of the frame's
+// sequence (graph launch), wait for its completion, copy of the results to the caller's arrays.
+int orbx_get_host_us(const orbx_t *h, float *us, int cap) {
+  if (!h || !us || cap < 4) return ORBX_E_ARG;
+  for (int i = 0; i < 4; i++) us[i] = h->host_us[i];
+  return 4;
 }
 
 // Known-traffic kernel for calibrating the HBM PMC counters in this library's access pattern (4 B per lane, the

@@ -102,6 +102,11 @@ int orbx_download_candidates(orbx_t *h, int frame, int level, float *xyr, int ca
 /* DistributeOctTree output of one level (ORBextractor.cc:859-860), list order, same coordinates. */
 int orbx_download_level_keypoints(orbx_t *h, int frame, int level, float *xyr, int cap);
 
+/* Host-side split of the last orbx_extract call, microseconds: us[0] copy of the image into pinned staging, us[1] submission of
+ * the frame's sequence (one graph launch), us[2] wait for its completion, us[3] copy of the results into the caller's arrays.
+ * Returns 4.  Diagnostic (tools/latency_breakdown.py); no counterpart in the reference. */
+int orbx_get_host_us(const orbx_t *h, float *us, int cap);
+
 /* Per-stage GPU time, measured with HIP events recorded on the stream the kernels were launched on.
  * orbx_set_profiling(h, 1) starts (or restarts) a recording; every extract call after it records one event set into a ring of
  * 32, and orbx_get_stage_ms returns the per-stage AVERAGE over the calls recorded since then (the 32 most recent): one

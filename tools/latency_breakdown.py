@@ -29,6 +29,12 @@ m.set_profiling(True); ex.set_profiling(True)
 for _ in range(20): search(); ex(frames[1], None, (0, 0))
 print("search (python call, tracking window): %.3f ms; kernels: %s" % (t_search * 1e3, {k: round(v, 4) for k, v in m.stage_ms().items()}))
 print("extract (python call): %.3f ms; kernels: %s  sum %.4f" % (t_ext * 1e3, {k: round(v, 4) for k, v in ex.stage_ms().items()}, sum(ex.stage_ms().values())))
+ex.set_profiling(False)
+acc = np.zeros(4)
+for _ in range(100):
+    ex(frames[1], None, (0, 0))
+    us = np.zeros(4, np.float32); ex.L.orbx_get_host_us(ex.h, us.ctypes.data_as(C.c_void_p), 4); acc += us
+print("extract host side, us: staging copy %.1f, submission %.1f, wait %.1f, copy-out %.1f" % tuple(acc / 100))
 # raw C call without the Python marshalling of search_window
 a = lambda x, t: np.ascontiguousarray(x, dtype=t)
 q = [a(args["qdesc"], np.uint8), a(args["u"], np.float32), a(args["v"], np.float32), a(args["radius"], np.float32), a(args["min_level"], np.int32), a(args["max_level"], np.int32)]
