@@ -75,6 +75,8 @@ enum CalibOp {
   CAL_SALU_ADD,       // s_add_u32 (scalar unit: one per CU?)
   CAL_SALU_AND64,     // s_and_b64 / s_bcnt1_i32_b64 (the mask arithmetic around ballots)
   CAL_DS_READ_U8,     // ds_read_u8 with a per-lane address (LDS issue rate as k_fast's gathers see it)
+  CAL_XOR_SGPR,       // v_xor_b32 with a scalar-register source (k_match_scan: candidate descriptor words in SGPRs)
+  CAL_BCNT_SGPR,      // v_bcnt_u32_b32 fed by such a xor is VGPR-only; this one counts a scalar source directly
   CAL_NUM_OPS
 };
 
@@ -87,7 +89,7 @@ static const char *const kCalibOpNames[CAL_NUM_OPS] = {
     "v_bitop3_b32", "v_cndmask_b32 (SGPR-pair mask)", "v_cndmask_b32 (vcc, scalar-written)", "v_add_f32", "v_mul_f32", "v_cvt_f32_u32",
     "v_add_co_u32", "v_min_f32/v_max_f32", "v_min3_f32", "v_max3_f32", "v_med3_f32", "v_pk_min_f16/v_pk_max_f16", "v_pk_fma_f16", "v_pk_add_f16",
     "v_min_f16/v_max_f16", "v_min_u16/v_max_u16", "v_cvt_f32_ubyte0", "v_sub_f32", "v_max3_u32", "v_pk_min_u16/v_pk_max_u16", "v_addc_co_u32",
-    "s_add_u32", "s_and_b64/s_bcnt1_i32_b64", "ds_read_u8"};
+    "s_add_u32", "s_and_b64/s_bcnt1_i32_b64", "ds_read_u8", "v_xor_b32 (SGPR source)", "v_bcnt_u32_b32 (SGPR source)"};
 
 #define CAL_INSTR_PER_TRIP 128
 
@@ -103,6 +105,8 @@ static const char *const kCalibOpNames[CAL_NUM_OPS] = {
 
 #define I_ADD(d) "v_add_u32 %" #d ", %" #d ", %16\n"
 #define I_XOR(d) "v_xor_b32 %" #d ", %" #d ", %16\n"
+#define I_XORS(d) "v_xor_b32 %" #d ", s20, %" #d "\n"
+#define I_BCNTS(d) "v_bcnt_u32_b32 %" #d ", s20, %" #d "\n"
 #define I_MINU(d) "v_min_u32 %" #d ", %" #d ", %16\n"
 #define I_MAXU(d) "v_max_u32 %" #d ", %" #d ", %17\n"
 #define I_PKMIN(d) "v_pk_min_i16 %" #d ", %" #d ", %16\n"
@@ -279,6 +283,8 @@ __global__ __launch_bounds__(256) void k_calib_valu(uint32_t *sink, unsigned lon
             : "v"(base), "v"(b)
             : "memory");
       }
+      if constexpr (OP == CAL_XOR_SGPR) asm volatile("s_mov_b32 s20, 0x5bd1e995\n" CAL_TRIP(I_XORS) CAL_OPERANDS, "s20");
+      if constexpr (OP == CAL_BCNT_SGPR) asm volatile("s_mov_b32 s20, 0x5bd1e995\n" CAL_TRIP(I_BCNTS) CAL_OPERANDS, "s20");
       if constexpr (OP == CAL_FAST_MIX)
         asm volatile(CAL_R16(I_PKMIN) CAL_R16(I_PKMIN) CAL_R16(I_PKMAX) CAL_R16(I_PKMIN) CAL_R16(I_PKMAD) CAL_R16(I_PKMIN) CAL_R16(I_ADD)
                          CAL_R16(I_ADD) CAL_OPERANDS);

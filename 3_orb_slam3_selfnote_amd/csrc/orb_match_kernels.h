@@ -225,31 +225,11 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       t = hi;
     }
   };
-  int base = 0;   // first candidate of the chunk in LDS (the lambda below reads it)
-  auto hamming_and_park = [&](int c, bool ok, uint32_t bits) {
-    const uint4 a = sDesc[2 * c], b = sDesc[2 * c + 1];
-    // one accumulating v_bcnt_u32_b32 per word: two independent chains of four, one add (the compiler's own
-    // choice is eight zero-based counts plus an add tree: three more vector instructions per candidate)
-    int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
-    d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
-    d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
-    d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
-    const int dist = d0 + d1;
-    const K t = ok ? KT::make(dist, cell_of(bits), base + c) : KT::NONE;
-    const bool pass = t < top[MATCH_TOPK - 1];
-    // A key below the lane's current 8th best is parked in `pend`; the sorted insertion (16 min/max) runs for the whole
-    // wavefront only when some lane would have to park a second one.  With 64 lanes nearly every candidate improves
-    // SOME lane's list, so inserting on the spot executes the network for almost every candidate; parked, it runs
-    // about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
-    const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
-    if (passMask) {
-      if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
-        insert(pend);
-        pend = KT::NONE;
-      }
-      pend = pass ? t : pend;
-    }
-  };
+  int base = 0;   // first candidate of the chunk in LDS
+  // Parked insertion (both candidate loops below): a key below the lane's current 8th best is parked in `pend`; the sorted
+  // insertion (16 min/max) runs for the whole wavefront only when some lane would have to park a second one.  With 64 lanes
+  // nearly every candidate improves SOME lane's list, so inserting on the spot executes the network for almost every candidate;
+  // parked, it runs about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
   // "Open" query: the cell window is the whole 64 x 48 grid, no level filter, and the float window reaches more than one grid
   // cell beyond the image bounds on every side, so |x - u| < r and |y - v| < r hold for every keypoint PosInGrid accepts
   // (those lie within half a cell of the bounds).  A wavefront whose live lanes are all open skips the per-candidate tests.
@@ -260,8 +240,16 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   const bool allOpen = MODE == SCAN_PLAIN && __builtin_amdgcn_ballot_w64(w.live && !open) == 0ull;
   const int nchunks = (n + MATCH_CH - 1) / MATCH_CH;
   const int chunk0 = (int)(((long long)nchunks * blockIdx.z) / gridDim.z), chunk1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / gridDim.z);
+#ifdef SCAN_STAMPS
+  long long st_stage = 0, st_comp = 0, st_t = __builtin_readcyclecounter();
+  const long long st_begin = st_t;
+#define SSTAMP(acc) do { const long long t_ = __builtin_readcyclecounter(); acc += t_ - st_t; st_t = t_; } while (0)
+#else
+#define SSTAMP(acc) do {} while (0)
+#endif
   for (base = chunk0 * MATCH_CH; base < min(n, chunk1 * MATCH_CH); base += MATCH_CH) {
     const int m = min(MATCH_CH, n - base);
+    SSTAMP(st_comp);
     __syncthreads();
     if (tid < 2 * m) sDesc[tid] = desc[(size_t)base * 2 + tid];
     const int m4 = (m + 3) & ~3;   // the candidate loop runs four at a time; the tail is padded with unusable entries (bits = 0)
@@ -279,15 +267,62 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       sMeta[tid] = c;
     }
     __syncthreads();
+    SSTAMP(st_stage);
     if (w.live) {
       const int m4u = __builtin_amdgcn_readfirstlane(m4);
       if (MODE == SCAN_PLAIN && allOpen) {
         // Every live lane's window contains the whole grid and has no level filter (BASELINE's 1000x1000 stress setting, or a
         // relocalisation-style wide search): GetFeaturesInArea returns every in-grid keypoint, so the only test left is the
         // candidate's own usable bit, which is the same for all lanes (a scalar branch).
-        for (int c = 0; c < m4u; c++) {
-          const uint32_t bits = sMeta[c].bits;
-          if (__builtin_amdgcn_readfirstlane((int)(bits << 7)) < 0) hamming_and_park(c, true, bits);
+        // The candidate is the same for all 64 lanes: its descriptor comes through the scalar cache into SGPRs (the LDS copy
+        // costs two 1-KiB broadcast reads per candidate and wavefront, and the LDS pipe is shared by the CU's 16 wavefronts).
+        // Four candidates per trip, nothing conditional in front of their distances: four scalar loads in flight together (one
+        // candidate at a time left each wavefront waiting out its own load), and ONE vote per trip on "does any of the four
+        // enter some lane's list" - after the first few hundred candidates it hardly ever does.  19 vector instructions per
+        // candidate and wavefront (8 xor with a scalar operand, 8 accumulating popcounts, 3 for the key); tools/scan_stamps.py.
+        const int baseu = __builtin_amdgcn_readfirstlane(base), nu = __builtin_amdgcn_readfirstlane(n);
+        auto hamming = [&](const uint4 a, const uint4 b) {
+          int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
+          d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
+          d0 = popc_acc(a.z ^ qd[2], d0); d1 = popc_acc(b.z ^ qd[6], d1);
+          d0 = popc_acc(a.w ^ qd[3], d0); d1 = popc_acc(b.w ^ qd[7], d1);
+          return d0 + d1;
+        };
+        auto key_of = [&](int dist, uint32_t bits, int idx) -> K {   // NONE for a keypoint outside the grid or already held (uniform)
+          const K unusable = (K)(((bits >> 24) & 1u)) - (K)1;                      // 0 or all ones; scalar arithmetic: bits and idx are uniform
+          return KT::make(dist, 0u, 0) | KT::make(0, cell_of(bits), idx) | unusable;
+        };
+        auto park = [&](K t) {
+          const bool pass = t < top[MATCH_TOPK - 1];
+          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);   // parked insertion, see above
+          if (passMask) {
+            if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
+              insert(pend);
+              pend = KT::NONE;
+            }
+            pend = pass ? t : pend;
+          }
+        };
+        for (int c = 0; c < m4u; c += 4) {
+          // (entries past the chunk's last candidate are unusable, bits = 0; their loads are clamped to the frame's last descriptor)
+          const int i0 = min(baseu + c, nu - 1), i1 = min(baseu + c + 1, nu - 1), i2 = min(baseu + c + 2, nu - 1), i3 = min(baseu + c + 3, nu - 1);
+          // (written as instructions: the compiler sinks a scalar load next to its first use and waits for each on its own)
+          typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+          u32x8 D0, D1, D2, D3;
+          asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx8 %2, %6, 0x0\n\ts_load_dwordx8 %3, %7, 0x0"
+                       : "=&s"(D0), "=&s"(D1), "=&s"(D2), "=&s"(D3)
+                       : "s"(desc + (size_t)i0 * 2), "s"(desc + (size_t)i1 * 2), "s"(desc + (size_t)i2 * 2), "s"(desc + (size_t)i3 * 2));
+          const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c].bits), s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 1].bits);
+          const uint32_t s2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 2].bits), s3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 3].bits);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(D0), "+s"(D1), "+s"(D2), "+s"(D3));
+          const uint4 a0 = make_uint4(D0[0], D0[1], D0[2], D0[3]), b0 = make_uint4(D0[4], D0[5], D0[6], D0[7]);
+          const uint4 a1 = make_uint4(D1[0], D1[1], D1[2], D1[3]), b1 = make_uint4(D1[4], D1[5], D1[6], D1[7]);
+          const uint4 a2 = make_uint4(D2[0], D2[1], D2[2], D2[3]), b2 = make_uint4(D2[4], D2[5], D2[6], D2[7]);
+          const uint4 a3 = make_uint4(D3[0], D3[1], D3[2], D3[3]), b3 = make_uint4(D3[4], D3[5], D3[6], D3[7]);
+          const K t0 = key_of(hamming(a0, b0), s0, baseu + c), t1 = key_of(hamming(a1, b1), s1, baseu + c + 1);
+          const K t2 = key_of(hamming(a2, b2), s2, baseu + c + 2), t3 = key_of(hamming(a3, b3), s3, baseu + c + 3);
+          const K tmin = min(min(t0, t1), min(t2, t3));
+          if (__builtin_amdgcn_ballot_w64(tmin < top[MATCH_TOPK - 1])) { park(t0); park(t1); park(t2); park(t3); }
         }
       } else {
       for (int c0 = 0; c0 < m4u; c0 += 4)
@@ -325,7 +360,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           const int dist = d0 + d1;
           const K t = ok ? KT::make(dist, cell_of(cm.bits), base + c) : KT::NONE;
           const bool pass = t < top[MATCH_TOPK - 1];
-          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);   // parked insertion, see hamming_and_park
+          const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);   // parked insertion, see above
           if (passMask) {
             if (passMask & __builtin_amdgcn_ballot_w64(pend != KT::NONE)) {
               insert(pend);
@@ -338,6 +373,10 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
       }
     }
   }
+  SSTAMP(st_comp);
+#ifdef SCAN_STAMPS
+  if (tid == 0 && M.dbg) { long long *d = M.dbg + 4 * (size_t)blockIdx.x; d[0] = st_stage; d[1] = st_comp; d[2] = st_t - st_begin; d[3] = st_begin; }
+#endif
   insert(pend);
   if (q < nq) {
     K *o = topk + (size_t)blockIdx.z * slice_stride + (qo + q) * MATCH_TOPK;

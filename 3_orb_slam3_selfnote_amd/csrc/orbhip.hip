@@ -982,7 +982,7 @@ struct orbm_handle {
     }                                                                                         \
   } while (0)
 
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS)
 static void *getenv_ptr(const char *name) { const char *e = getenv(name); return e ? (void *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
 
@@ -1183,7 +1183,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS)
   M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
 #endif
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
