@@ -46,6 +46,15 @@ struct LevelGeom {
   uint32_t rowTileMagic;  // floor(2^32 / row tiles of k_resize), see xcd_map
 };
 
+// k_pyramid_chain (single-frame calls): one record per 32x32 output tile of a level L >= 1.  rect[l] = the rectangle of level l
+// (l < L: everything the tile needs of that level, derived on the host from the resize tables; l = L: the tile itself).
+#define CHAIN_TILE 32
+#define CHAIN_NT 1024
+struct ChainTile {
+  uint16_t level, pad;
+  uint16_t x[ORB_MAXL], y[ORB_MAXL], w[ORB_MAXL], h[ORB_MAXL];
+};
+
 struct FrameParams {
   LevelGeom geom[ORB_MAXL];  // by value: lives in the kernarg segment, so every geometry access is a scalar load
   int nlevels;
@@ -75,6 +84,8 @@ struct FrameParams {
   int totalCells;                   // FAST cells per frame
   int totalKp;                      // sum of kpCap
   int octCap;                       // node capacity of the octree kernel
+  const ChainTile *chain;           // k_pyramid_chain's tile records
+  int chainBuf0, chainBuf1;         // bytes of its two LDS level buffers (even / odd levels)
   // outputs
   void *out_kps;       // orbx_keypoint_t [nframes][cap]
   uint8_t *out_desc;   // [nframes][cap][32]

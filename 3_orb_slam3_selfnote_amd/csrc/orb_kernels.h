@@ -254,6 +254,73 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K1, single-frame form.  A frame on its own is latency: seven dependent k_resize launches of a few microseconds each cost more
+// in launch-to-launch gaps than in work.  Here ONE launch makes every level: a workgroup owns a 32x32 tile of level L and
+// recomputes, in LDS, the rectangles of levels 1..L-1 that tile depends on (sizes grow 1.2x per level down: 141x141 of level 0
+// for a level-7 tile), each from the one below with exactly k_resize's arithmetic on exactly its table entries - a level's pixel
+// is the same function of the same bytes whoever computes it, so the planes are byte-identical.  About 10x the arithmetic of
+// the level-by-level form, on a chip that a single frame leaves empty; batches keep k_resize.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CHAIN_NT) void k_pyramid_chain(FrameParams P) {
+  extern __shared__ __align__(16) uint8_t smem_ch[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = CHAIN_NT / 64;
+  const int ntile = (int)gridDim.x / P.nframes;
+  const int frame = (int)blockIdx.x / ntile, tile = (int)blockIdx.x - frame * ntile;
+  __shared__ ChainTile T;   // indexed by level at run time: LDS, not registers
+  static_assert(sizeof(ChainTile) % 4 == 0 && sizeof(ChainTile) / 4 <= CHAIN_NT, "one dword per thread");
+  if (tid < (int)(sizeof(ChainTile) / 4)) reinterpret_cast<uint32_t *>(&T)[tid] = reinterpret_cast<const uint32_t *>(&P.chain[tile])[tid];
+  __syncthreads();
+  const int L = T.level;
+  uint8_t *buf[2] = {smem_ch, smem_ch + P.chainBuf0};
+  int2 *sTab = reinterpret_cast<int2 *>(smem_ch + P.chainBuf0 + P.chainBuf1);   // per level 1..L: x entries of rect[l], then y entries
+  // table slices of every stage, one memory latency for all of them
+  {
+    int off = 0;
+    for (int l = 1; l <= L; l++) {
+      const LevelGeom &G = P.geom[l];
+      for (int i = tid; i < T.w[l] + T.h[l]; i += CHAIN_NT)
+        sTab[off + i] = i < T.w[l] ? P.xtab[G.xtabBase + T.x[l] + i] : P.ytab[G.ytabBase + T.y[l] + (i - T.w[l])];
+      off += T.w[l] + T.h[l];
+    }
+  }
+  // rect[0] of the caller's image -> buffer 0 (rows by wavefront, columns by lane)
+  {
+    const uint8_t *img = P.img0 + (size_t)frame * P.img0_frame_stride + (size_t)T.y[0] * P.img0_stride + T.x[0];
+    const int rw = T.w[0], rh = T.h[0];
+    for (int r = wid; r < rh; r += NW)
+      for (int c = lane; c < rw; c += 64) buf[0][r * rw + c] = img[(size_t)r * P.img0_stride + c];
+  }
+  __syncthreads();
+  int toff = 0;
+  for (int l = 1; l <= L; l++) {
+    const LevelGeom &G = P.geom[l];
+    const LevelGeom &Gs = P.geom[l - 1];
+    const int rw = T.w[l], rh = T.h[l], sw = T.w[l - 1], sx0 = T.x[l - 1], sy0 = T.y[l - 1];
+    const uint8_t *S = buf[(l - 1) & 1];
+    uint8_t *D = buf[l & 1];
+    const int2 *sX = sTab + toff, *sY = sX + rw;
+    toff += rw + rh;
+    uint8_t *plane = P.pyr + (size_t)frame * P.pyr_fs + G.off + (size_t)T.y[l] * G.pitch + T.x[l];
+    const float inv_rw = 1.0f / (float)rw;
+    for (int idx = tid; idx < rw * rh; idx += CHAIN_NT) {       // idx < 2^14: (idx + 0.5) / rw truncates to the exact quotient (see k_resize)
+      const int ry = (int)(((float)idx + 0.5f) * inv_rw), rx = idx - ry * rw;
+      const int2 xt = sX[rx], yt = sY[ry];
+      const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+      const int sya = min(max(yt.x, 0), Gs.h - 1), syb = min(max(yt.x + 1, 0), Gs.h - 1);
+      const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff, b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+      const uint8_t *S0 = S + (sya - sy0) * sw - sx0, *S1 = S + (syb - sy0) * sw - sx0;
+      const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+      const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+      const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      if (l == L) plane[(size_t)ry * G.pitch + rx] = (uint8_t)v;
+      else D[idx] = (uint8_t)v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 per cell (ORBextractor.cc:787-854 + cv::FAST).
 //
 // Threshold-free formulation.  For a pixel with centre v and circle c_k let

@@ -70,12 +70,14 @@ struct orbx_handle {
   std::vector<LevelGeom> geom;
   size_t pyr_fs = 0, blur_fs = 0, slot_fs = 0;
   bool octCellsLds = false;
+  int chainTiles = 0, chainBuf0 = 0, chainBuf1 = 0;   // k_pyramid_chain (single-frame calls); chainTiles = 0: not available
+  size_t chainLds = 0;
   size_t octLds = 0;
   int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
   DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_tiles, d_xtab,
-      d_ytab, d_disc;
+      d_ytab, d_disc, d_chain;
   DevBuf d_img, d_okps;  // staging for the host entry point (d_okps: counts + keypoints + descriptors, one block)
   hipStream_t stream = nullptr;
   float host_us[4] = {0, 0, 0, 0};          // orbx_extract's last call: staging copy, submission, wait, copy-out (orbx_get_host_us)
@@ -246,7 +248,7 @@ void orbx_destroy(orbx_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
-                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_img, &h->d_okps};
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_chain, &h->d_img, &h->d_okps};
   for (DevBuf *b : bufs) b->release();
   for (DevBuf &b : h->stereo) b.release();
   for (DevBuf &b : h->maps) b.release();
@@ -463,6 +465,54 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_ytab.reserve(sizeof(int2) * std::max<size_t>(ytab.size(), 1)));
   if (!xtab.empty()) XCHECK(h, copy_on(h->stream, h->d_xtab.p, xtab.data(), sizeof(int2) * xtab.size(), hipMemcpyHostToDevice));
   if (!ytab.empty()) XCHECK(h, copy_on(h->stream, h->d_ytab.p, ytab.data(), sizeof(int2) * ytab.size(), hipMemcpyHostToDevice));
+  // k_pyramid_chain's tile records: for every 32x32 tile of a level L >= 1 the rectangles of levels L-1 .. 0 it depends on,
+  // walked down through the resize tables exactly as k_resize indexes them (x: sx, min(sx+1, w-1); y: clamp(sy), clamp(sy+1))
+  {
+    std::vector<ChainTile> tilesC;
+    size_t b0 = 0, b1 = 0, tabMax = 0;
+    for (int L = nl - 1; L >= 1; L--)   // highest level first: its workgroups have the longest chains and must not start last
+      for (int ty = 0; ty < g[L].h; ty += CHAIN_TILE)
+        for (int tx = 0; tx < g[L].w; tx += CHAIN_TILE) {
+          ChainTile T;
+          memset(&T, 0, sizeof(T));
+          T.level = (uint16_t)L;
+          int x0 = tx, x1 = std::min(tx + CHAIN_TILE, g[L].w) - 1, y0 = ty, y1 = std::min(ty + CHAIN_TILE, g[L].h) - 1;   // inclusive
+          size_t tab = 0;
+          for (int l = L; l >= 0; l--) {
+            T.x[l] = (uint16_t)x0; T.y[l] = (uint16_t)y0; T.w[l] = (uint16_t)(x1 - x0 + 1); T.h[l] = (uint16_t)(y1 - y0 + 1);
+            const size_t area = (size_t)T.w[l] * T.h[l];
+            if (l < L) { if (l & 1) b1 = std::max(b1, area); else b0 = std::max(b0, area); }
+            if (l == 0) break;
+            tab += (size_t)T.w[l] + T.h[l];
+            const int sw = g[l - 1].w, sh = g[l - 1].h;
+            const int2 *xt = &xtab[g[l].xtabBase], *yt = &ytab[g[l].ytabBase];
+            int nx0 = sw, nx1 = 0, ny0 = sh, ny1 = 0;
+            for (int x = x0; x <= x1; x++) { nx0 = std::min(nx0, xt[x].x); nx1 = std::max(nx1, std::min(xt[x].x + 1, sw - 1)); }
+            for (int y = y0; y <= y1; y++) {
+              ny0 = std::min(ny0, std::min(std::max(yt[y].x, 0), sh - 1));
+              ny1 = std::max(ny1, std::min(std::max(yt[y].x + 1, 0), sh - 1));
+            }
+            x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
+          }
+          tabMax = std::max(tabMax, tab);
+          tilesC.push_back(T);
+        }
+    b0 = align_up(b0, 16); b1 = align_up(b1, 16);
+    const size_t lds = b0 + b1 + sizeof(int2) * tabMax;
+    // stage sizes stay below 2^14 pixels (the kernel's index split) and the whole state inside 64 KiB; otherwise (scale factors far
+    // from 1.2) single-frame calls keep the level-by-level form
+    h->chainTiles = 0;
+    if (!tilesC.empty() && lds <= 64 * 1024 && b1 <= 16384 && b0 <= 65536 && tilesC.size() < 65536) {
+      bool ok = true;
+      for (const ChainTile &T : tilesC)
+        for (int l = 1; l <= T.level; l++) ok = ok && (size_t)T.w[l] * T.h[l] < 16384;
+      if (ok) {
+        XCHECK(h, h->d_chain.reserve(sizeof(ChainTile) * tilesC.size()));
+        XCHECK(h, copy_on(h->stream, h->d_chain.p, tilesC.data(), sizeof(ChainTile) * tilesC.size(), hipMemcpyHostToDevice));
+        h->chainTiles = (int)tilesC.size(); h->chainBuf0 = (int)b0; h->chainBuf1 = (int)b1; h->chainLds = lds;
+      }
+    }
+  }
   // k_octree LDS: node arrays (72 B per node) + scan scratch, plus the level's cell offsets when they fit
   int maxCells = 1;
   for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, g[l].nCols * g[l].nRows);
@@ -557,6 +607,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   P.magicKpBlk = magic_div((uint32_t)std::max((h->totalKp + 3) / 4, 1));
   P.totalKp = h->totalKp;
   P.octCap = h->octCap;
+  P.chain = (const ChainTile *)h->d_chain.p; P.chainBuf0 = h->chainBuf0; P.chainBuf1 = h->chainBuf1;
   P.out_kps = d_kps;
   P.out_desc = d_desc;
   P.out_counts = d_counts;
@@ -564,6 +615,11 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   const bool prof = h->profiling && h->ev_ok;
   hipEvent_t *pev = h->ev[h->prof_head % PROF_DEPTH];
   if (prof) XCHECK(h, hipEventRecord(pev[0], s));
+  // One workgroup per (frame, level) in k_octree and one launch per level here: a batch fills the chip that way; a single frame is
+  // all launch gaps and one long workgroup, so few-frame calls ("wide") take the one-launch pyramid and 1024-thread octree.
+  const bool wide = (long long)h->nlevels * nframes <= 32;
+  if (wide && h->chainTiles > 0) hipLaunchKernelGGL(k_pyramid_chain, dim3(h->chainTiles * nframes), dim3(CHAIN_NT), h->chainLds, s, P);
+  else
   for (int l = 1; l < h->nlevels; l++) {
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
@@ -573,9 +629,8 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[2], s));
-  // One workgroup per (frame, level).  A batch fills the chip with 256-thread workgroups; a single frame has only nlevels of them
-  // and the longest (level 0) is the critical path of the whole call, so few-frame launches use 1024 threads per workgroup.
-  const bool wide = (long long)h->nlevels * nframes <= 32;
+  // (k_octree: one workgroup per (frame, level); a single frame has only nlevels of them and the longest, level 0, is the critical
+  // path of the whole call, so few-frame launches use 1024 threads per workgroup)
   if (wide) {
     if (h->octCellsLds) hipLaunchKernelGGL((k_octree<1024, true>), dim3(h->nlevels * nframes), dim3(1024), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);
     else hipLaunchKernelGGL((k_octree<1024, false>), dim3(h->nlevels * nframes), dim3(1024), h->octLds, s, P, (uint32_t *)h->d_cellOff.p);

@@ -2,8 +2,8 @@
 """Vector-issue ceiling of each product kernel for ITS OWN opcode mix -> profiles/valu_mix.json (runs on the CPU: hipcc -S).
 
 The per-class issue rates are measured (profiles/valu_calib.json, csrc/orb_calib.h): on gfx950 a handful of simple opcodes
-(v_add/sub_u32, v_and/or/xor_b32, v_lshrrev_b32, v_mov_b32, v_add/mul/fma_f32, v_bitop3_b32) issue a wave64 instruction every 2
-cycles per SIMD, nearly everything else (min/max, compares, selects, packed 16-bit, dot, perm, bcnt, mul24/mad, three-operand
+(v_add/sub_u32, v_and/or/xor_b32, v_lshrrev_b32, v_mov_b32, v_add/mul/fma_f32, v_min/max_u16, v_bitop3_b32) issue a wave64
+instruction every 2 cycles per SIMD - unless one of their sources is a scalar register, then every 4 -, nearly everything else (min/max, compares, selects, packed 16-bit, dot, perm, bcnt, mul24/mad, three-operand
 integer forms, shifts left, conversions) every 4 - and the hardware counters do not tell the two apart (SQ_ACTIVE_INST_VALU ==
 SQ_INSTS_VALU for both, tools/check_valu_counters.py).  So the mix is taken from the code object: every VALU instruction of a
 kernel is weighted by 10^(loop depth of its basic block) (LLVM's loop annotations in the assembly) and priced with the measured
@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
          "--cuda-device-only", "-S"]
 KERNELS = {"k_resize": r"^_Z8k_resize", "k_fast": r"^_Z6k_fast", "k_octree": r"^_Z8k_octreeILi256ELb1E", "k_blur": r"^_Z6k_blur",
-           "k_describe": r"^_Z10k_describe", "k_match_scan": r"^_Z12k_match_scanI5Key32Li0E", "k_match_resolve": r"^_Z15k_match_resolveI5Key32Lb1E",
+           "k_describe": r"^_Z10k_describe", "k_match_scan": r"^_Z12k_match_scanI5Key32Li0E", "k_match_walk": r"^_Z12k_match_walkI5Key32Li0E", "k_match_resolve": r"^_Z15k_match_resolveI5Key32Lb1E",
            "k_lastframe_project": r"^_Z19k_lastframe_project", "k_rot_prune": r"^_Z11k_rot_prune"}
 # opcode (suffix-stripped) -> name of the calibration class that measured it
 CLASS_OF = {
@@ -39,10 +39,11 @@ CLASS_OF = {
     "v_cndmask_b32": "v_cndmask_b32 (SGPR-pair mask)", "v_add3_u32": "v_add3_u32", "v_and_or_b32": "v_and_or_b32", "v_lshl_or_b32": "v_lshl_or_b32",
     "v_bfe_u32": "v_bfe_u32", "v_bfe_i32": "v_bfe_u32", "v_min3_u32": "v_min3_u32", "v_med3_i32": "v_med3_i32", "v_sad_u8": "v_sad_u8",
     "v_cvt_f32_u32": "v_cvt_f32_u32", "v_cvt_f32_i32": "v_cvt_f32_u32", "v_add_co_u32": "v_add_co_u32", "v_fma_f64": "v_fma_f64",
-    "v_fmac_f64": "v_fma_f64", "v_mul_f64": "v_fma_f64", "v_add_f64": "v_fma_f64",
+    "v_fmac_f64": "v_fma_f64", "v_mul_f64": "v_fma_f64", "v_add_f64": "v_fma_f64", "v_min_u16": "v_min_u16/v_max_u16", "v_max_u16": "v_min_u16/v_max_u16",
 }
 CMP = re.compile(r"^v_cmpx?_")
 SUFFIX = re.compile(r"(_e32|_e64|_sdwa|_dpp|_e64_dpp)$")
+SGPR_SRC = re.compile(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc(_lo|_hi)?|exec(_lo|_hi)?|m0)(?![\w])")
 
 
 def assembly():
@@ -93,6 +94,9 @@ def main():
                 cls = "v_cndmask_b32"            # reads VCC: the slow form (measured 16 cycles)
             else:
                 cls = CLASS_OF.get(base)
+            # a full-rate opcode that reads a scalar register issues at the half rate (measured: "v_xor_b32 (SGPR source)")
+            if cls in rate and rate[cls] > 1.3 * half and SGPR_SRC.search(" ".join(t[2:]).split(";")[0]):
+                cls = "v_xor_b32 (SGPR source)" if "v_xor_b32 (SGPR source)" in rate else "v_pk_min_i16/v_pk_max_i16"
             if cls is None or cls not in rate:
                 unknown[base] += w
                 cls = None
