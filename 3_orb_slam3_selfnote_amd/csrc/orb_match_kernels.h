@@ -413,8 +413,12 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
 #define WALK_LIST 16   // passing candidates a lane collects before it computes their distances
 struct WalkRec { float x, y; uint32_t w; };   // w = octave | gx << 4 | gy << 10 | usable << 16 | keypoint index << 17
 
-template <typename KT, int MODE>
-__global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, typename KT::T *topk, int force, int capn /* LDS rows: >= every n, <= WALK_MAX_N */) {
+// LPQ = lanes per query.  1: a batch (one lane walks a query's whole window).  4: few pairs in flight (single-frame calls) - the
+// columns of a window are dealt to four adjacent lanes, whose lists lane 0 merges: the walk is a serial chain per lane, and
+// a quarter of the columns is a quarter of the chain; four times the workgroups stage the frame, on CUs that are idle anyway.
+template <typename KT, int MODE, int LPQ>
+__global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, typename KT::T *topk, int force, int capn /* LDS rows: >= every n, <= WALK_MAX_N */,
+                                                         int wqblocks /* query blocks of MATCH_NT / LPQ queries per pair */) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_walk[];
   __shared__ int sVote;
@@ -423,12 +427,13 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, type
   long long wt0 = __builtin_readcyclecounter();
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const unsigned b = blockIdx.x, qblocks = (unsigned)M.scan_qblocks;   // same XCD-aware order as k_match_scan
+  constexpr int QW = MATCH_NT / LPQ;   // queries per workgroup
+  const unsigned b = blockIdx.x, qblocks = (unsigned)wqblocks;   // same XCD-aware order as k_match_scan
   const int qb = (int)((b >> 3) % qblocks), p = (int)((b & 7u) + 8u * (b / (8u * qblocks)));
   if (p >= M.npairs) return;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
-  if ((int)(qb * MATCH_NT) >= nq) return;
+  if ((int)(qb * QW) >= nq) return;
   if (!pair_walks(M, p, n, nq, force, &sVote)) return;
   WSTAMP(0);
   const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, type
   WalkRec *sRec = reinterpret_cast<WalkRec *>(smem_walk + GRID_CELLS + 4);
   float *sUr = reinterpret_cast<float *>(sRec + capn);
   uint16_t *sList = reinterpret_cast<uint16_t *>(sUr + (NEEDUR ? capn : 0));   // [WALK_LIST][MATCH_NT]
+  K *sMerge = reinterpret_cast<K *>(sList + WALK_LIST * MATCH_NT);              // [MATCH_NT][MATCH_TOPK], LPQ > 1 only
   for (int c = tid; c < GRID_CELLS + 4; c += MATCH_NT) sCell[c] = 0u;
   __syncthreads();
   // ---- counting sort by cell: histogram (the atomic's return value is the keypoint's rank inside its cell) ...
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, type
   __syncthreads();
   WSTAMP(3);
   // ---- every query walks its window
-  const int q = qb * MATCH_NT + tid;
+  const int q = qb * QW + tid / LPQ, sub = tid % LPQ;
   if (q >= nq) return;
   const QueryWin w = load_query(M, qo, q);
   const int nleft = STEREO && M.qside ? M.nleft : n;
@@ -515,12 +521,13 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, type
     // order): lanes advance independently, so a wavefront runs as long as its busiest lane, not as the sum over columns of the
     // busiest lane per column.  Candidates that pass every test are only noted; their descriptors are fetched and compared
     // WALK_LIST at a time - the Hamming distance and the top-8 insertion run for the few that pass, not once per visited cell entry.
-    int ix = w.cx0, j = (int)sCell[ix * 48 + w.cy0], j1 = (int)sCell[ix * 48 + w.cy1 + 1], cnt = 0;
-    bool more = w.cx0 <= w.cx1;   // (a NaN or negative radius gives an empty column range: no candidates, as in the reference's loops)
+    int ix = w.cx0 + sub, cnt = 0;
+    bool more = ix <= w.cx1;      // (a NaN or negative radius gives an empty column range: no candidates, as in the reference's loops)
+    int j = more ? (int)sCell[ix * 48 + w.cy0] : 0, j1 = more ? (int)sCell[ix * 48 + w.cy1 + 1] : 0;
     for (;;) {
       if (more) {
         if (j >= j1) {
-          if (++ix > w.cx1) more = false;
+          if ((ix += LPQ) > w.cx1) more = false;
           else { j = (int)sCell[ix * 48 + w.cy0]; j1 = (int)sCell[ix * 48 + w.cy1 + 1]; }
         } else {
           const WalkRec rec = sRec[j];
@@ -575,6 +582,29 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_walk(MatchProblemSet M, type
     }
   }
   WSTAMP(4);
+  if (LPQ > 1) {
+    // the LPQ lanes of a query sit side by side in one wavefront and left the loop together: lists through LDS (same-wavefront
+    // LDS traffic is ordered), lane 0 of the group folds the others' sorted lists into its own and stops at the first key that
+    // cannot enter
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) sMerge[tid * MATCH_TOPK + j] = top[j];
+    const unsigned long long anyMask = __builtin_amdgcn_ballot_w64(any);
+    any = ((anyMask >> (lane & ~(LPQ - 1))) & ((1ull << LPQ) - 1ull)) != 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (sub != 0) return;
+    for (int sl = 1; sl < LPQ; sl++)
+      for (int j = 0; j < MATCH_TOPK; j++) {
+        K t = sMerge[(tid + sl) * MATCH_TOPK + j];
+        if (t >= top[MATCH_TOPK - 1]) break;
+#pragma unroll
+        for (int k2 = 0; k2 < MATCH_TOPK; k2++) {
+          const K lo = t < top[k2] ? t : top[k2];
+          const K hi = t < top[k2] ? top[k2] : t;
+          top[k2] = lo;
+          t = hi;
+        }
+      }
+  }
   K *o = topk + (qo + q) * MATCH_TOPK;
 #pragma unroll
   for (int j = 0; j < MATCH_TOPK; j++) o[j] = top[j];

@@ -141,8 +141,10 @@ static hipError_t raise_lds_limits(int device) {
   std::lock_guard<std::mutex> lock(mu);
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
   if (done[device]) return hipSuccess;
-  const void *fns[] = {reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_PLAIN>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_UR>),
-                       reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FISHEYE>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FUSE>),
+  const void *fns[] = {reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_PLAIN, 1>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_UR, 1>),
+                       reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FISHEYE, 1>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FUSE, 1>),
+                       reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_PLAIN, 4>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_UR, 4>),
+                       reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FISHEYE, 4>), reinterpret_cast<const void *>(&k_match_walk<Key32, SCAN_FUSE, 4>),
                        reinterpret_cast<const void *>(&k_octree<256, true>), reinterpret_cast<const void *>(&k_octree<256, false>),
                        reinterpret_cast<const void *>(&k_octree<1024, true>), reinterpret_cast<const void *>(&k_octree<1024, false>),
                        reinterpret_cast<const void *>(&k_resize),
@@ -1282,9 +1284,17 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const int force = !k32 ? SCAN_DENSE : (m->next_scan_mode >= 0 ? m->next_scan_mode : m->scan_mode);
   m->next_scan_mode = -1;
   const int capn = std::min((maxn + 7) & ~7, WALK_MAX_N);
-  const size_t wlds = sizeof(uint32_t) * (GRID_CELLS + 4) + (12 + (fuse || M.u_right ? 4 : 0)) * (size_t)capn + 2 * WALK_LIST * MATCH_NT;
-  const dim3 wgrid(8 * qblocks * ((npairs + 7) / 8));
-#define LAUNCH_WALK(MODE) hipLaunchKernelGGL((k_match_walk<Key32, MODE>), wgrid, dim3(MATCH_NT), wlds, s, M, (Key32::T *)m->d_topk.p, force, capn)
+  // few pairs in flight: four lanes per query and four times the workgroups (see k_match_walk)
+  const int lpq = (long long)npairs * qblocks <= 32 ? 4 : 1;
+  const int wqblocks = (maxq + MATCH_NT / lpq - 1) / (MATCH_NT / lpq);
+  const size_t wlds = sizeof(uint32_t) * (GRID_CELLS + 4) + (12 + (fuse || M.u_right ? 4 : 0)) * (size_t)capn + 2 * WALK_LIST * MATCH_NT +
+                      (lpq > 1 ? sizeof(uint32_t) * MATCH_TOPK * MATCH_NT : 0);
+  const dim3 wgrid(8 * wqblocks * ((npairs + 7) / 8));
+#define LAUNCH_WALK(MODE)                                                                                                                                    \
+  do {                                                                                                                                                        \
+    if (lpq > 1) hipLaunchKernelGGL((k_match_walk<Key32, MODE, 4>), wgrid, dim3(MATCH_NT), wlds, s, M, (Key32::T *)m->d_topk.p, force, capn, wqblocks);      \
+    else hipLaunchKernelGGL((k_match_walk<Key32, MODE, 1>), wgrid, dim3(MATCH_NT), wlds, s, M, (Key32::T *)m->d_topk.p, force, capn, wqblocks);               \
+  } while (0)
   if (force != SCAN_DENSE) {
     if (fuse) LAUNCH_WALK(SCAN_FUSE); else if (M.qside) LAUNCH_WALK(SCAN_FISHEYE); else if (M.u_right) LAUNCH_WALK(SCAN_UR); else LAUNCH_WALK(SCAN_PLAIN);
   }
