@@ -104,14 +104,17 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 }
 
 // inclusive scan inside a wavefront
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    uint32_t t = __shfl_up(v, o, WAVE);
-    if (lane >= o) v += t;
-  }
-  return v;
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  // DPP: row_shr 1, 2, 4, 8 scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals on (six vector instructions;
+  // the __shfl_up form is six trips through the LDS crossbar)
+  int v = (int)x;
+  v += dpp_or_zero<0x111, 0xf>(v);
+  v += dpp_or_zero<0x112, 0xf>(v);
+  v += dpp_or_zero<0x114, 0xf>(v);
+  v += dpp_or_zero<0x118, 0xf>(v);
+  v += dpp_or_zero<0x142, 0xa>(v);
+  v += dpp_or_zero<0x143, 0xc>(v);
+  return (uint32_t)v;
 }
 
 // Exclusive scan of an LDS array a[0..n) in place using all NT threads (blockDim.x == NT, 1-D block).
@@ -127,13 +130,12 @@ __device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
     uint32_t inc = wave_incl_scan(v);
     if (lane == 63) sw[wid] = inc;
     __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      uint32_t s = sw[w];
-      if (w < wid) woff += s;
-      tot += s;
-    }
+    // the NW wave totals are scanned in registers by every wavefront (one LDS read per lane instead of NW per thread)
+    const uint32_t wsum = lane < NW ? sw[lane] : 0u;
+    const uint32_t wincl = wave_incl_scan(wsum);
+    const int widu = __builtin_amdgcn_readfirstlane(wid);
+    const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wsum), widu);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wincl, NW - 1);
     if (i < n) a[i] = carry + woff + inc - v;
     carry += tot;
     __syncthreads();
@@ -390,8 +392,10 @@ __device__ __forceinline__ int fast_compass_sign(const uint8_t *c, int t) {  // 
 #define FAST_LIST_SEG 888   // list entries per wavefront: 15 rows x 59 columns (64-lane rows), 16 rows x 32 (32-lane rows)
 static_assert(FAST_NT == 256, "k_fast's list segments assume four wavefronts");
 // Diagnostic builds (-DFAST_STAMPS, tools/fast_stamps.py): cycles per section, thread 0 of every workgroup.
-#ifdef FAST_STAMPS
+#if defined(FAST_STAMPS) || defined(OCT_STAMPS)
 __device__ unsigned int *g_fast_stamps;  // [workgroup][8] cycle deltas, set by orbx_debug_fast_stamps
+#endif
+#ifdef FAST_STAMPS
 #define FSTAMP(i) do { const long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && g_fast_stamps) g_fast_stamps[(size_t)blockIdx.x * 8 + (i)] = (unsigned int)(t_ - ft0); ft0 = t_; } while (0)
 #else
 #define FSTAMP(i) do {} while (0)
@@ -593,11 +597,19 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 //    taken with a 64-bit LDS atomicMax over (response, ~index).
 // Candidates are first compacted from the per-cell slot lists into the reference's vToDistributeKeys order.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef OCT_STAMPS   // diagnostic builds only (tools/octree_stamps.py): cycles per phase, thread 0 of every workgroup, summed over the rounds
+#define OSTAMP(i) do { const long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && g_fast_stamps) g_fast_stamps[(size_t)blockIdx.x * 8 + (i)] += (unsigned int)(t_ - ot0); ot0 = t_; } while (0)
+#else
+#define OSTAMP(i) do {} while (0)
+#endif
 struct OctNode { short ulx, urx, uly, bry; };
 
 template <int NT, bool CELLS_LDS>
 __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffScratch) {
   extern __shared__ __align__(16) uint8_t smem[];
+#ifdef OCT_STAMPS
+  long long ot0 = __builtin_readcyclecounter();
+#endif
   const int CAP = P.octCap;
   // carve (all offsets multiples of 8)
   unsigned long long *best = reinterpret_cast<unsigned long long *>(smem);          // aliases chcnt/chpos
@@ -640,8 +652,10 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     uint32_t inc = wave_incl_scan(v);
     if (lane == 63) sw[wid] = inc;
     __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (int w = 0; w < NW; w++) { uint32_t s = sw[w]; if (w < wid) woff += s; tot += s; }
+    const uint32_t wsum = lane < NW ? sw[lane] : 0u;       // wave totals scanned in registers, as in lds_excl_scan
+    const uint32_t wincl = wave_incl_scan(wsum);
+    const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wsum), __builtin_amdgcn_readfirstlane(wid));
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wincl, NW - 1);
     if (i < ncell) { if (CELLS_LDS) cellOffL[i] = carry + woff + inc - v; else cellOffG[i] = carry + woff + inc - v; }
     carry += tot;
     __syncthreads();
@@ -673,6 +687,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     }
   }
   __syncthreads();
+  OSTAMP(0);
 
   // ---- B. root nodes (ORBextractor.cc:541-585) ----
   const int nIni = G.nIni;
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   for (int k = tid; k < n; k += NT) knode[k] = (uint16_t)chpos[knode[k]];
   int L = shI[0];
   __syncthreads();
+  OSTAMP(1);
 
   // ---- C. rounds ----
   const int N = G.N;
@@ -734,6 +750,24 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
       }
     }
     __syncthreads();
+    OSTAMP(2);
+    // A full round (every node with more than one key is split, in list order: rank order = list order) needs three prefix sums
+    // over the list - expandable nodes before me, their children before me, unprocessed nodes before me - and gets them from ONE
+    // scan of packed counters (10 + 12 + 10 bits: lists below 1024 nodes); careful rounds, which rank by size, keep three scans.
+    int mstar, Eproc, Lnew;
+    const bool fusedScan = !careful && L < 1024;
+    if (fusedScan) {
+      for (int i = tid; i < L; i += NT) {
+        const bool e = cnts[i] > 1;
+        const uint32_t c = e ? (chcnt[i * 4] > 0) + (chcnt[i * 4 + 1] > 0) + (chcnt[i * 4 + 2] > 0) + (chcnt[i * 4 + 3] > 0) : 0u;
+        sflag[i] = (e ? 1u : 0u) | (c << 10) | ((e ? 0u : 1u) << 22);
+      }
+      __syncthreads();
+      const uint32_t tot = lds_excl_scan<NT>(sflag, L, sw);
+      mstar = (int)(tot & 1023u) - 1;
+      Eproc = (int)((tot >> 10) & 4095u);
+      Lnew = Eproc + (int)(tot >> 22);
+    } else {
     // rank of the expandable nodes in processing order
     if (!careful) {
       for (int i = tid; i < L; i += NT) sflag[i] = cnts[i] > 1 ? 1u : 0u;
@@ -742,19 +776,24 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
       for (int i = tid; i < L; i += NT) rankOf[i] = cnts[i] > 1 ? (int)sflag[i] : -1;
       if (tid == 0) shI[3] = (int)nX;
     } else {
+      // rank by (size descending, list position ascending) = the number of expandable nodes that go first: four adjacent lanes
+      // per node, each counting over a quarter of the list, summed across the quad (DPP)
       uint32_t myX = 0;
-      for (int i = tid; i < L; i += NT) {
-        uint32_t ci = cnts[i];
-        int r = -1;
-        if (ci > 1) {
-          r = 0;
-          for (int j = 0; j < L; j++) {
-            uint32_t cj = cnts[j];
+      for (int i0 = 0; i0 < L; i0 += NT / 4) {
+        const int i = i0 + (tid >> 2), part = tid & 3;
+        const uint32_t ci = i < L ? cnts[i] : 0u;
+        int r = 0;
+        if (ci > 1)
+          for (int j = part; j < L; j += 4) {
+            const uint32_t cj = cnts[j];
             r += (cj > 1 && (cj > ci || (cj == ci && j < i))) ? 1 : 0;
           }
-          myX++;
+        r += __builtin_amdgcn_update_dpp(0, r, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        r += __builtin_amdgcn_update_dpp(0, r, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        if (i < L && part == 0) {
+          rankOf[i] = ci > 1 ? r : -1;
+          if (ci > 1) myX++;
         }
-        rankOf[i] = r;
       }
       myX = (uint32_t)wave_sum_i32((int)myX);
       if (lane == 0 && myX) atomicAdd(&shI[1], (int)myX);
@@ -785,7 +824,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
       }
     }
     __syncthreads();
-    int mstar = nX - 1;
+    mstar = nX - 1;
     if (careful && shI[2] != 0x7fffffff) mstar = shI[2];
     // Eproc = inclusive sum at mstar; unprocessed flags
     for (int i = tid; i < L; i += NT) {
@@ -799,17 +838,27 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     }
     if (tid == 0 && nX == 0) shI[4] = 0;
     __syncthreads();
-    const int Eproc = shI[4];
+    Eproc = shI[4];
     uint32_t nUnproc = lds_excl_scan<NT>(sflag, L, sw);
-    const int Lnew = Eproc + (int)nUnproc;
+    Lnew = Eproc + (int)nUnproc;
+    }
+    OSTAMP(3);
     // build the next list
     for (int i = tid; i < L; i += NT) {
-      int r = rankOf[i];
       OctNode o = nodes[i];
-      if (r >= 0 && r <= mstar) {
+      bool proc;
+      uint32_t childrenBefore, unprocBefore;
+      if (fusedScan) {
+        const uint32_t pk = sflag[i];
+        proc = cnts[i] > 1; childrenBefore = (pk >> 10) & 4095u; unprocBefore = pk >> 22;
+      } else {
+        const int r = rankOf[i];
+        proc = r >= 0 && r <= mstar; childrenBefore = proc ? incl[r] : 0u; unprocBefore = sflag[i];
+      }
+      if (proc) {
         uint32_t c0 = chcnt[i * 4], c1 = chcnt[i * 4 + 1], c2 = chcnt[i * 4 + 2], c3 = chcnt[i * 4 + 3];
         uint32_t c = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
-        int pos = Eproc - (int)(incl[r] + c);  // block start; inside the block n4,n3,n2,n1
+        int pos = Eproc - (int)(childrenBefore + c);  // block start; inside the block n4,n3,n2,n1
         int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;
         int nexp = 0;
         uint32_t cc[4] = {c0, c1, c2, c3};
@@ -832,12 +881,13 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
         if (nexp) atomicAdd(&shI[1], nexp);
         npos[i] = -1;
       } else {
-        int pos = Eproc + (int)sflag[i];
+        int pos = Eproc + (int)unprocBefore;
         if (pos < CAP) { nodesN[pos] = o; cntsN[pos] = cnts[i]; }
         npos[i] = pos;
       }
     }
     __syncthreads();
+    OSTAMP(4);
     // re-label the keys
     for (int k = tid; k < n; k += NT) {
       int nd = knode[k];
@@ -854,6 +904,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     }
     const int nToExpand = shI[1];
     __syncthreads();
+    OSTAMP(5);
     { OctNode *t = nodes; nodes = nodesN; nodesN = t; }
     { uint32_t *t = cnts; cnts = cntsN; cntsN = t; }
     L = min(Lnew, CAP);
@@ -893,6 +944,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     lrank[i] = (uint16_t)((f << 15) | (rank & 0x7fff));
   }
   if (tid == 0) { lcnt[0] = Lout; lcnt[1] = (int)nLap; }
+  OSTAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -289,8 +289,8 @@ int orbx_get_features_per_level(const orbx_t *h, int *n) {
 // floor(2^32 / n) for xcd_map's division by multiplication (n == 1: the estimate q-1 is corrected on the device)
 static uint32_t magic_div(uint32_t n) { return n <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / n); }
 
-#ifdef FAST_STAMPS
-// diagnostic builds only (tools/fast_stamps.py): device buffer [workgroups][8] of u32 cycle deltas per k_fast section
+#if defined(FAST_STAMPS) || defined(OCT_STAMPS)
+// diagnostic builds only (tools/fast_stamps.py, tools/octree_stamps.py): device buffer [workgroups][8] of u32 cycle deltas per k_fast section
 int orbx_debug_fast_stamps(void *d_buf) {
   unsigned int *p = (unsigned int *)d_buf;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
