@@ -692,14 +692,14 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long v)
 // only when an unlisted candidate could change the decision:
 //   no survivor          and an unlisted one could be within th_dist;
 //   one survivor (best)  and the unknown second-best could make the ratio test fail (ORBmatcher.cc:126).
-template <typename KT>
+template <typename KT, int STRIDE = 64>
 __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typename KT::T *sTkLane, uint32_t vm, uint32_t cm,
                                            uint32_t oct4, bool truncated, int lbDist, int *bd_out) {
   typedef typename KT::T K;
   const uint32_t av = vm & ~cm, av2 = av & (av - 1u);
   const int found = __popc(av);
   const int j1 = (__ffs((int)av) - 1) & (MATCH_TOPK - 1), j2 = (__ffs((int)av2) - 1) & (MATCH_TOPK - 1);
-  const K best = sTkLane[64 * j1], second = sTkLane[64 * j2];
+  const K best = sTkLane[STRIDE * j1], second = sTkLane[STRIDE * j2];
   const int l1 = (int)((oct4 >> (4 * j1)) & 0xfu), l2 = (int)((oct4 >> (4 * j2)) & 0xfu);
   const int bd = found > 0 ? KT::dist(best) : 256;
   bool rescan = false;
@@ -740,7 +740,7 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 #define REFRESH_K 4
 #define REQ_WORDS 16  // lane, flags, u, v, r, ur, minl, maxl, descriptor[8]
 template <typename KT, bool LDSCAND>
-__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn) {
+__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn, int rforce) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
   __shared__ K sTk[MATCH_TOPK * 64];
@@ -915,6 +915,206 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     }
     (void)target;
   };
+  // ---- Wide form (tracking-sized windows, monocular / rectified-stereo problems) ------------------------------------------------------
+  // The chunked form below resolves 64 queries at a time on ONE wavefront: with sparse conflicts its time is the number of
+  // chunks times (a dozen global loads + two or three rounds of LDS round trips), all of it latency on a single wavefront while
+  // seven wait.  The same fix-point holds for any number of lanes: here every thread of the workgroup is a lane (512 queries per
+  // super-chunk), "claimed for me" is still owner <= my index, a round is separated by workgroup barriers instead of wavefront
+  // ones, and the settled prefix / first exhausted lane are found through two LDS words.  Conflict chains are short, so a
+  // super-chunk settles in three or four rounds - a 1000-query frame in 8 rounds instead of 48.  Exhausted lists are refreshed
+  // by the whole workgroup exactly as below (serve()).  Used when no query's window exceeds WALK_MAX_CELLS grid cells (the rule
+  // of k_match_walk: few candidates per query, few exhausted lists); the stress setting keeps the chunked form, whose refresh
+  // passes are cheaper per pass.
+  __shared__ int sVoteR;
+  constexpr bool WIDE_OK = sizeof(K) == 4;   // Key32 only: frames of at most 2048 keypoints (the wide list array is 16 KiB)
+  constexpr int WN = 64 * RESOLVE_NW;
+  __shared__ K sTkW[WIDE_OK ? MATCH_TOPK * WN : 1];
+  __shared__ int sRmin[4], sChg[4], sTake, sNm;   // sRmin / sChg: a ring over the rounds (see below)
+  bool wide = false;
+  if (WIDE_OK && !M.serial && !M.partner && M.couple == 0 && !M.qside && rforce != SCAN_DENSE) {
+    if (rforce == SCAN_WALK) wide = true;
+    else {   // pair_walks' vote with this kernel's block size
+      if (tid == 0) sVoteR = 0;
+      __syncthreads();
+      int big = n > WALK_MAX_N ? 1 : 0;
+      for (int q = tid; q < nq; q += WN) {
+        const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
+        const float u = M.qu[qo + q], v = M.qv[qo + q], r = M.qr[qo + q];
+        const int cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w)), cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
+        const int cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h)), cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
+        const bool live = (fl & 1) && cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0;
+        if (live && (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > WALK_MAX_CELLS) big = 1;
+      }
+      if (big) sVoteR = 1;
+      __syncthreads();
+      wide = sVoteR == 0;
+    }
+  }
+  if (wide) {
+    if (tid == 0) { for (int i = 0; i < 4; i++) { sRmin[i] = 0x7fffffff; sChg[i] = 0; } sTake = 0; sNm = 0; }
+    __syncthreads();
+    int nmatches = 0;
+    for (int base = 0; base < nq; base += WN) {
+      const int q = base + tid;
+      const int cnt = min(WN, nq - base);
+      const uint32_t myfl = q < nq ? (M.qflags ? M.qflags[qo + q] : 3u) : 0u;
+      const bool ob = (myfl >> 1) & 1u;
+      uint32_t qpar[6] = {0, 0, 0, 0, 0, 0}, qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < MATCH_TOPK; j++) sTkW[WN * j + tid] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+      if (q < nq) {
+        qpar[0] = __float_as_uint(M.qu[qo + q]); qpar[1] = __float_as_uint(M.qv[qo + q]); qpar[2] = __float_as_uint(M.qr[qo + q]);
+        qpar[3] = __float_as_uint(M.qur ? M.qur[qo + q] : 0.f);
+        qpar[4] = (uint32_t)M.qminl[qo + q]; qpar[5] = (uint32_t)M.qmaxl[qo + q];
+        const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
+        const uint4 a = qp[0], b = qp[1];
+        qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+      }
+      int eidx[MATCH_TOPK];
+      uint32_t vm, oct4;
+      int capm1 = MATCH_TOPK - 1, lbDist;
+      bool truncated;
+      auto load_list = [&]() {   // own column only: no barrier needed between its write and this read
+        vm = 0; oct4 = 0;
+#pragma unroll
+        for (int j = 0; j < MATCH_TOPK; j++) {
+          const K t = sTkW[WN * j + tid];
+          eidx[j] = n;
+          if (t != KT::NONE) {
+            const int idx = KT::idx(t);
+            eidx[j] = idx;
+            vm |= 1u << j;
+            oct4 |= (uint32_t)(octave_of(idx) & 0xf) << (4 * j);
+          }
+        }
+        const K last = sTkW[WN * capm1 + tid];
+        truncated = last != KT::NONE;
+        lbDist = KT::dist(last);
+        if (!(myfl & 1u)) { vm = 0; truncated = false; }
+      };
+      load_list();
+      // fresh lists for every lane with `want`, RESOLVE_NW requests per pass, all wavefronts serving (serve() as in the chunked form)
+      auto refresh = [&](bool want) {
+        bool todo = want;
+        for (;;) {
+          __syncthreads();                       // sTake == 0 here (reset at the end of the previous pass / at start)
+          int slot = -1;
+          if (todo) slot = atomicAdd(&sTake, 1);
+          const bool take = todo && slot < RESOLVE_NW;
+          if (take) {
+            uint32_t *R = sReq[slot];
+            R[0] = (uint32_t)tid; R[1] = myfl;
+#pragma unroll
+            for (int t = 0; t < 6; t++) R[2 + t] = qpar[t];
+#pragma unroll
+            for (int t = 0; t < 8; t++) R[8 + t] = qd[t];
+          }
+          __syncthreads();
+          const int asked = sTake;
+          if (asked == 0) break;                 // uniform: nobody left
+          const int m = min(RESOLVE_NW, asked);
+          {
+            const int np = shares_of(m), mp = RESOLVE_NW / np, rq = wid & (mp - 1);
+            if (rq < m) serve(rq, wid / mp, np);
+          }
+          __syncthreads();
+          if (tid == 0) sTake = 0;
+          if (take) {
+            static_assert(REFRESH_K == 4, "the merge network below is written for 4 keys");
+            auto cx = [](K &lo, K &hi) { const K l = lo < hi ? lo : hi, h = lo < hi ? hi : lo; lo = l; hi = h; };
+            const int np = shares_of(m);
+            K a[REFRESH_K];
+#pragma unroll
+            for (int j = 0; j < REFRESH_K; j++) a[j] = sPart[slot][0][j];
+            for (int sh = 1; sh < np; sh++) {
+#pragma unroll
+              for (int j = 0; j < REFRESH_K; j++) {
+                const K y = sPart[slot][sh][REFRESH_K - 1 - j];
+                a[j] = a[j] < y ? a[j] : y;
+              }
+              cx(a[0], a[2]); cx(a[1], a[3]);
+              cx(a[0], a[1]); cx(a[2], a[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < MATCH_TOPK; j++) sTkW[WN * j + tid] = j < REFRESH_K ? a[j] : KT::NONE;
+            todo = false;
+            capm1 = REFRESH_K - 1;
+            load_list();
+          }
+        }
+      };
+      uint32_t D = 0;
+      int my_bd = 256, res_idx = -1, res_bd = 256;
+      int s = 0, par = 0;
+      bool first_round = true;
+      while (s < cnt) {
+        int r;
+        for (;;) {
+          const bool pend = tid >= s && tid < cnt;
+          const bool post = pend && (D >> 31) && ob;
+          const int bidx = (int)(D & 0xfffffu);
+          if (post) __hip_atomic_fetch_min(&sOwner[bidx], (uint32_t)(tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __syncthreads();
+          uint32_t cm = 0;
+#pragma unroll
+          for (int j = 0; j < MATCH_TOPK; j++) cm |= (sOwner[eidx[j]] <= (uint32_t)tid ? 1u : 0u) << j;
+          const uint32_t mine = sOwner[post ? bidx : n];
+          __syncthreads();
+          if (post && mine != 0u) sOwner[bidx] = RESOLVE_FREE;     // withdraw (a claim committed meanwhile, 0, must survive)
+          const uint32_t nD = pend ? decide<KT, WN>(M, sTkW + tid, vm, cm, oct4, truncated, lbDist, &my_bd) : D;
+          const bool changed = nD != D;
+          D = nD;
+          const bool flagged = pend && ((D >> 30) & 1u);
+          // first exhausted lane, then "did anything at or before it change": two LDS words per round, taken from a ring of four -
+          // a round's words are cleared two rounds later, when every thread is past the barriers behind which it read them
+          const int cur = par & 3;
+          par++;
+          if (tid == 0) { sRmin[(cur + 2) & 3] = 0x7fffffff; sChg[(cur + 2) & 3] = 0; }
+          if (flagged) atomicMin(&sRmin[cur], tid);
+          __syncthreads();
+          r = min(sRmin[cur], cnt);
+          if (first_round) {
+            first_round = false;
+            if (r < cnt) {             // exhausted by the claims of earlier super-chunks: refresh them all at once, decide again
+              refresh(flagged);
+              continue;
+            }
+          }
+          if (changed && tid <= r) sChg[cur] = 1;
+          __syncthreads();
+          if (sChg[cur] == 0) break;
+        }
+        // commit the settled prefix [s, r)
+        {
+          const bool inpre = tid >= s && tid < r;
+          const bool acc = inpre && (D >> 31);
+          const int bidx = (int)(D & 0xfffffu);
+          nmatches += __popcll(__ballot(acc));
+          if (acc) {
+            const int32_t sv = (int32_t)(((uint32_t)q << 1) | (ob ? 1u : 0u));
+            if (ob) sOwner[bidx] = 0u;
+            __hip_atomic_fetch_max(&sSlot[bidx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (inpre) { res_idx = acc ? bidx : -1; res_bd = my_bd <= M.th_dist ? my_bd : 256; }
+        }
+        s = r;
+        if (r < cnt) refresh(tid >= r && tid < cnt && ((D >> 30) & 1u));   // lane r is first in line now: with its fresh list it decides next round
+        else __syncthreads();                                              // commits visible before the next super-chunk's first round
+      }
+      if (q < nq) {
+        if (M.match_of_query) M.match_of_query[qo + q] = res_idx;
+        if (M.best_dist) M.best_dist[qo + q] = res_bd;
+      }
+    }
+    if (lane == 0 && nmatches) atomicAdd(&sNm, nmatches);
+    __syncthreads();
+    if (tid == 0 && M.nmatches) M.nmatches[p] = sNm;
+    for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+      const int32_t v = sSlot[i];
+      if (v >= 0) { slot[i] = v >> 1; slot_obs[i] = (uint8_t)(v & 1); }
+    }
+    return;
+  }
 #ifdef RESOLVE_STAMPS
   long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0;
   long long t0 = __builtin_readcyclecounter();

@@ -1275,9 +1275,9 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   // resolve LDS: owner words (n + 1 dummy), slot words, column-sorted keypoint list (u16), partner list, octave bytes; see k_match_resolve
   const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
   const size_t big = small + sizeof(uint32_t) * (size_t)((maxn + 3) / 4) + 48 * (size_t)maxn;   // + octave bytes, records, descriptors
-  const bool ldscand = big <= 150 * 1024;
+  const bool ldscand = big <= 136 * 1024;   // + the kernel's static LDS (Key32: wide list array 16 KiB, chunk lists, requests)
   const size_t lds = ldscand ? big : small;
-  if (lds > 160 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
+  if (lds > 152 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
   const dim3 rblock(64 * RESOLVE_NW);
   // Window walk (k_match_walk) or full scan (k_match_scan): decided per pair on the device unless a mode is forced; frames beyond
   // 2048 keypoints (Key64) are always scanned.  The walk's workgroups come first: they are the short ones.
@@ -1311,7 +1311,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
     else                                                                                                                  \
-      hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn);   \
+      hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn, force);   \
   } while (0)
   if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
   else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
