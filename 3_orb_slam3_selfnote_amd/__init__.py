@@ -11,6 +11,7 @@ The package name starts with a digit (it is fixed by the project layout), so imp
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -264,8 +265,10 @@ class ORBextractor:
         kps = np.zeros(cap, dtype=KP_DTYPE)
         desc = np.zeros((cap, 32), dtype=np.uint8)
         n = C.c_int(0)
+        t0 = time.perf_counter()
         rc = self.L.orbx_extract(self.h, _p(image), rows, cols, C.c_size_t(image.strides[0]), int(vLappingArea[0]),
                                  int(vLappingArea[1]), _p(kps), _p(desc), cap, C.byref(n))
+        self.last_call_s = time.perf_counter() - t0   # the C call alone (what a C++ caller of the adapter pays), for tools/run_sequence.py
         if rc == E_EMPTY:
             return -1, kps[:0], desc[:0]
         if rc == E_CAP:
@@ -486,10 +489,12 @@ class ORBmatcher:
         fs = frame.struct()
         moq = np.full(nq, -1, dtype=np.int32)
         bd = np.full(nq, 256, dtype=np.int32)
+        t0 = time.perf_counter()
         rc = self.L.orbm_search_by_projection(self.m, C.byref(fs), C.byref(qs),
                                               C.c_float(self.mfNNratio if nnratio is None else nnratio),
                                               int(self.TH_HIGH if th_dist is None else th_dist), int(bool(use_second)),
                                               _p(frame.slot), _p(frame.slot_obs), _p(moq), _p(bd))
+        self.last_call_s = time.perf_counter() - t0   # the C call alone, for tools/run_sequence.py
         self._check(rc, "orbm_search_by_projection")
         if rc < 0:
             raise OrbError("orbm_search_by_projection rc=%d" % rc)

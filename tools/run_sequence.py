@@ -8,7 +8,8 @@ SearchByProjection against the previous frame (what Tracking::TrackWithMotionMod
                                                        # DIR/mav0/cam0/data/<timestamp>.png, as mono_euroc.cc:66 loads them
 
 Prints what mono_euroc.cc prints at the end (median / mean tracking time, :183-190) for the front-end part and writes a CSV
-`frame, n_keypoints, n_matches, ORB_Ext(ms), Match(ms)`.  Everything runs through the host-pointer C ABI (the drop-in
+`frame, n_keypoints, n_matches, ORB_Ext(ms), Match(ms), ORB_Ext_C(ms), Match_C(ms)` (the last two: the C call alone, as the
+reference's own `ORB_Ext` timer sees its C++ call, Frame.cc:333-343).  Everything runs through the host-pointer C ABI (the drop-in
 path of the adapter: one image in, keypoints + descriptors out), so the numbers are PCIe- and sync-inclusive.
 GPU box only; PNG decoding needs Pillow (datasets are not part of this repository)."""
 import argparse
@@ -63,6 +64,7 @@ def main():
         t0 = time.perf_counter()
         _, kps, desc = ex(im, None, (0, 0))
         t1 = time.perf_counter()
+        c_ext, c_mat = ex.last_call_s, 0.0
         nmatch = 0
         if prev is not None and len(kps) and len(prev[0]):
             pk, pd = prev
@@ -72,17 +74,22 @@ def main():
             # zero-motion prediction: last frame's keypoints projected where they were; window th = 15 px * scale (Tracking.cc:2898)
             nmatch, _, _ = mt.search_window(F, pd, pk["x"], pk["y"], (15.0 * sf[lvl]).astype(np.float32), lvl - 1, lvl + 1,
                                             nnratio=0.9, th_dist=100, use_second=False)
+            c_mat = mt.last_call_s
         t2 = time.perf_counter()
-        rows.append((name, len(kps), int(nmatch), (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+        rows.append((name, len(kps), int(nmatch), (t1 - t0) * 1e3, (t2 - t1) * 1e3, c_ext * 1e3, c_mat * 1e3))
         prev = (kps, desc)
     os.makedirs(os.path.dirname(args.csv) or ".", exist_ok=True)
     with open(args.csv, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["frame", "n_keypoints", "n_matches", "ORB_Ext(ms)", "Match(ms)"])
+        w.writerow(["frame", "n_keypoints", "n_matches", "ORB_Ext(ms)", "Match(ms)", "ORB_Ext_C(ms)", "Match_C(ms)"])
         w.writerows(rows)
     ext = np.array([r[3] for r in rows[1:]]); mat = np.array([r[4] for r in rows[1:]])
+    cext = np.array([r[5] for r in rows[1:]]); cmat = np.array([r[6] for r in rows[1:]])
     print("frames: %d   keypoints/frame: %.0f   matches/frame: %.0f" % (len(rows), np.mean([r[1] for r in rows]), np.mean([r[2] for r in rows[1:]])))
-    print("median front-end time: %.3f ms   (ORB_Ext %.3f ms, match %.3f ms)" % (np.median(ext + mat), np.median(ext), np.median(mat)))
+    # the reference times the C++ call (Frame.cc:333-343): the C ABI calls alone, then the same with this Python mirror's marshalling
+    print("C ABI calls (orbx_extract + orbm_search_by_projection): median %.3f ms   (ORB_Ext %.3f ms, match %.3f ms), mean %.3f ms" % (
+        np.median(cext + cmat), np.median(cext), np.median(cmat), np.mean(cext + cmat)))
+    print("median front-end time: %.3f ms   (ORB_Ext %.3f ms, match %.3f ms)   [incl. the Python mirror's array handling]" % (np.median(ext + mat), np.median(ext), np.median(mat)))
     print("mean front-end time:   %.3f ms" % np.mean(ext + mat))
     ex.close(); mt.close()
 
