@@ -2,10 +2,11 @@
 //
 // Kernel inventory (roofline per kernel in DESIGN.md):
 //   k_resize    K1  cv::resize INTER_LINEAR 8U, one pyramid level of every frame per launch
-//   k_fast      K2  FAST-9/16 score + per-cell NMS + per-cell threshold fallback, one workgroup per 30-px cell
+//   k_pyramid_chain K1  the same planes in ONE launch for single-frame calls (a tile recomputes the levels below it in LDS)
+//   k_fast      K2  FAST-9/16 score + per-cell NMS, cell detected at iniThFAST and again at minThFAST if empty, one workgroup per 30-px cell
 //   k_octree    K3  DistributeOctTree, one workgroup per (frame, level), node list in LDS
-//   k_blur      K5  7x7 sigma-2 fixed-point Gaussian, 64x16 tiles staged through LDS
-//   k_describe  K4+K6+K7  IC_Angle + steered BRIEF + lapping-order scatter, one wavefront (64 lanes) per keypoint
+//   k_blur      K5  7x7 sigma-2 fixed-point Gaussian, 128x32 tiles staged through LDS
+//   k_describe  K4+K6+K7  IC_Angle + steered BRIEF + lapping-order scatter + frame totals, one wavefront (64 lanes) per keypoint
 // All arithmetic is integer or non-contracted IEEE fp32/fp64 (hipcc -ffp-contract=off) so results are bit-exact
 // against the CPU restatement the tests use.  No MFMA: this is byte/bit work bound by HBM, LDS and VALU integer rate.
 #pragma once

@@ -39,7 +39,7 @@ struct MatchProblemSet {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Projection search = two kernels.
+// Projection search = candidate lists (k_match_scan, or k_match_walk for tracking-sized windows) + k_match_resolve.
 //
 // The reference resolves queries strictly in order because a keypoint claimed by an earlier map point is skipped by
 // later ones (ORBmatcher.cc:89-91/:130, :2135-2137/:2162).  Claims only ever REMOVE candidates, so:

@@ -93,8 +93,8 @@ struct orbx_handle {
   // pinned host staging of the single-frame entry point (orbx_extract): pageable copies would serialise on HIP's own staging
   void *pin_in = nullptr, *pin_out = nullptr;
   size_t pin_in_bytes = 0, pin_out_bytes = 0;
-  // the per-frame sequence of orbx_extract (H2D, 12 launches, 3 D2H) captured once per configuration as a hipGraph:
-  // one submission per frame instead of 16
+  // the per-frame sequence of orbx_extract (H2D, 5 launches, 1 D2H) captured once per configuration as a hipGraph:
+  // one submission per frame instead of 7
   hipGraphExec_t graph = nullptr;
   struct { int rows = 0, cols = 0, lap0 = 0, lap1 = 0, icap = 0; const void *pin_in = nullptr, *pin_out = nullptr, *d_img = nullptr, *d_okps = nullptr, *d_pyr = nullptr; } graph_key;
   bool graph_ok = true;   // cleared (for good) if capture / instantiation fails: the plain path is used instead
