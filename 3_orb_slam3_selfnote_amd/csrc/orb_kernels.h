@@ -11,6 +11,7 @@
 // against the CPU restatement the tests use.  No MFMA: this is byte/bit work bound by HBM, LDS and VALU integer rate.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "orb_common.h"
 #include "orb_sincos.h"
 
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const float inv_qw = 1.0f / (float)qw;
   // The row loop is instantiated twice so that the source gathers are ds_read_u8 (LDS) or global_load_ubyte; one loop
   // with a run-time pointer select compiles to FLAT loads that wait on both counters.
-  auto rows = [&](auto srcRow) {
+  auto rows = [&](auto srcRow, auto lds) {
+    // LDS rows: column w exists (the rows are padded to 16-byte chunks) and is only ever read with weight a1 = 0 (the table clamps
+    // sx to w - 1 with fx = 0 there), so the second tap is the byte next to the first - an address offset, not a second address
+    constexpr bool LDSROWS = decltype(lds)::value;
     for (int q = tid; q < qw * nrows; q += 256) {
       const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
       const int2 yt = sY[ry];
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int2 xt = sX[dx0 + j];            // columns past the row end repeat the last one (padded table); only [0, w) is stored
-        const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+        const int sx = xt.x, sx1 = LDSROWS ? sx + 1 : min(sx + 1, Gs.w - 1);
         const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
         const int r0 = S0[sx] * a0 + S0[sx1] * a1;
         const int r1 = S1[sx] * a0 + S1[sx1] * a1;
@@ -252,8 +256,8 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
       else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
     }
   };
-  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + mul24((uint32_t)(sy - syFirst), (uint32_t)smemRowBytes); });
-  else rows([&](int sy) { return src + mul24((uint32_t)sy, (uint32_t)spitch); });  // extreme scale factors: straight from global
+  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + mul24((uint32_t)(sy - syFirst), (uint32_t)smemRowBytes); }, std::true_type());
+  else rows([&](int sy) { return src + mul24((uint32_t)sy, (uint32_t)spitch); }, std::false_type());  // extreme scale factors: straight from global
 }
 
 // ------------------------------------------------------------------------------------------------------------
