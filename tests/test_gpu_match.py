@@ -656,3 +656,63 @@ def test_search_by_bow_fisheye_n3(pkg, oracle, synth, nodes):
         assert (m_ref[len(kl):] >= 0).sum() > 50 and (m_ref[:len(kl)] >= 0).sum() > 50     # both images receive matches
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("npairs", [2, 12])
+def test_batch_pairs_vote_independently(pkg, oracle, synth, npairs):
+    """orbm_search_by_projection_batch_device with frame pairs of BOTH kinds in one launch: even pairs search tracking-sized
+    windows (the device vote sends them to k_match_walk and the wide resolve), odd pairs a window covering the frame
+    (k_match_scan, chunked resolve).  Every pair must equal the oracle run on that pair alone: the vote is taken per pair and must
+    come out the same in the walk, the scan, the list merge (2 pairs: the sliced scan of few-pair launches) and the resolve."""
+    import ctypes as C
+    import torch
+    frames, offs = synth.make_stream(4200, npairs + 1)
+    o = oracle.OracleExtractor(**EUROC)
+    ext = [o.extract(f)[1:] for f in frames]
+    sf = np.asarray(o.scale_factors, dtype=np.float32)
+    cap = max(len(k) for k, _ in ext) + 5
+    kp = np.zeros((npairs + 1, cap, 7), dtype=np.float32)
+    de = np.zeros((npairs + 1, cap, 32), dtype=np.uint8)
+    cnt = np.zeros((npairs + 1, 2), dtype=np.int32)
+    for i, (k, d) in enumerate(ext):
+        n = len(k)
+        kp[i, :n] = np.ascontiguousarray(k).view(np.float32).reshape(n, 7)
+        de[i, :n] = d
+        cnt[i, 0] = n
+    u = np.zeros((npairs, cap), np.float32); v = np.zeros((npairs, cap), np.float32); rad = np.zeros((npairs, cap), np.float32)
+    lo = np.zeros((npairs, cap), np.int32); hi = np.zeros((npairs, cap), np.int32)
+    for p in range(npairs):                  # queries = frame p's keypoints, searched in frame p + 1
+        k = ext[p][0]; n = len(k)
+        u[p, :n] = k["x"] + np.float32(offs[p][0] - offs[p + 1][0]); v[p, :n] = k["y"] + np.float32(offs[p][1] - offs[p + 1][1])
+        lvl = k["octave"].astype(np.int32)
+        if p % 2 == 0:
+            rad[p, :n] = 15.0 * sf[lvl]; lo[p, :n] = lvl - 1; hi[p, :n] = lvl + 1
+        else:
+            rad[p, :n] = 1.0e4; lo[p, :n] = -1; hi[p, :n] = -1
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_kp, d_de, d_cnt, d_u, d_v, d_r, d_lo, d_hi = t(kp), t(de), t(cnt), t(u), t(v), t(rad), t(lo), t(hi)
+    slot = torch.full((npairs, cap), -1, dtype=torch.int32, device=dev); sobs = torch.zeros((npairs, cap), dtype=torch.uint8, device=dev)
+    moq = torch.full((npairs, cap), -7, dtype=torch.int32, device=dev); bd = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
+    nm = torch.zeros((npairs,), dtype=torch.int32, device=dev)
+    m = pkg.ORBmatcher(0.8, True)
+    try:
+        fs = pkg.FrameStruct(cap, d_kp[1:].data_ptr(), d_de[1:].data_ptr(), None, 0.0, 752.0, 0.0, 480.0)
+        qs = pkg.QueryStruct(cap, d_de.data_ptr(), d_u.data_ptr(), d_v.data_ptr(), d_r.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), None, None)
+        rc = m.L.orbm_search_by_projection_batch_device(m.m, C.byref(fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
+                                                        C.c_void_p(d_cnt.data_ptr()), 2, npairs, C.c_float(0.8), 100, 1,
+                                                        C.c_void_p(slot.data_ptr()), C.c_void_p(sobs.data_ptr()), C.c_void_p(moq.data_ptr()),
+                                                        C.c_void_p(bd.data_ptr()), C.c_void_p(nm.data_ptr()), None)
+        assert rc == 0, m.L.orbm_last_error(m.m)
+        torch.cuda.synchronize()
+        moq_h, bd_h, nm_h, slot_h = moq.cpu().numpy(), bd.cpu().numpy(), nm.cpu().numpy(), slot.cpu().numpy()
+        for p in range(npairs):
+            (k0, d0), (k1, d1) = ext[p], ext[p + 1]
+            n0, n1 = len(k0), len(k1)
+            OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, (0.0, 752.0, 0.0, 480.0), o.scale_factors)
+            n_ref, moq_ref, bd_ref = OF.search_by_projection_win(d0, u[p, :n0], v[p, :n0], rad[p, :n0], lo[p, :n0], hi[p, :n0], 0.8, 100, True)
+            assert nm_h[p] == n_ref and n_ref > 200, "pair %d" % p
+            assert np.array_equal(moq_h[p, :n0], moq_ref) and np.array_equal(bd_h[p, :n0], bd_ref), "pair %d" % p
+            assert np.array_equal(slot_h[p, :n1], OF.slot), "pair %d" % p
+    finally:
+        m.close()
