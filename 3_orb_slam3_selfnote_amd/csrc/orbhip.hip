@@ -1546,6 +1546,16 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
   dl.obs = obs ? dp + pObs.off : nullptr;
   dl.Tcw = (const float *)(dp + pTc.off); dl.Tlw = (const float *)(dp + pTl.off);
   m->ext = {};
+  // The windows are th * scale factor of the last keypoint's octave (ORBmatcher.cc:2109): known here, so the walk-or-scan decision
+  // is taken on the host from the largest one (an upper bound of every query's cell window) and only the chosen kernels are launched
+  if (m->scan_mode == SCAN_AUTO && n <= WALK_MAX_N && cur->max_x > cur->min_x && cur->max_y > cur->min_y) {
+    float rmax = 0.f;
+    for (int i = 0; i < nLast; i++)
+      if (has_mp[i]) rmax = std::max(rmax, th * sf[last_keys[i].octave]);
+    const float iw = (float)ORBM_GRID_COLS / (cur->max_x - cur->min_x), ih = (float)ORBM_GRID_ROWS / (cur->max_y - cur->min_y);
+    const long long cx = std::min<long long>(ORBM_GRID_COLS, (long long)ceilf(2.f * rmax * iw) + 2), cy = std::min<long long>(ORBM_GRID_ROWS, (long long)ceilf(2.f * rmax * ih) + 2);
+    if (cx * cy <= WALK_MAX_CELLS) m->next_scan_mode = SCAN_WALK;
+  }
   int rc = orbm_search_by_projection_last_frame_batch_device(m, &df, n, nullptr, 0, &dl, nLast, nullptr, 0, 1, sf, nlevels, cam_type, cam_params, mb, mbf,
                                                              th, bMono, checkOri, (int32_t *)(dp + pSlot.off), dp + pSobs.off, nullptr,
                                                              (int32_t *)(dp + pNm.off), s);
