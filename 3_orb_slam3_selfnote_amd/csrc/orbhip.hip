@@ -1052,6 +1052,7 @@ orbm_t *orbm_create(int device) {
   orbm_handle *m = new orbm_handle();
   m->device = device;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return nullptr; }
+  if (const char *e = getenv("ORBM_SCAN_MODE")) { const int v = atoi(e); if (v >= SCAN_AUTO && v <= SCAN_WALK) m->scan_mode = v; }   // measurements only; see orbm_set_scan_mode
   return m;
 }
 

@@ -9,9 +9,9 @@ Workloads (`--config`):
   tumvi  BASELINE configs[4]: 512x512, 1500 features, last-frame SearchByProjection (ORBmatcher.cc:2027-2289) whose windows come
          from KannalaBrandt8::project with the TUM_512.yaml:9-19 parameters, th 15; map points resident in HBM.
 
-A batch = B frames that are already resident in HBM: 12 extraction launches + the search launches on one stream.  A STEP =
-`--batches-per-step` batches (default 32 x 256 = 8192 frames per GPU), dealt round-robin to `--streams` independent pipelines, so
-that the driver's 20-step run keeps the GPU busy for about a second.  The batches of a step cycle through `--groups` different
+A batch = B frames that are already resident in HBM: 11 extraction launches + the search launches on one stream.  A STEP =
+`--batches-per-step` batches (default 48 x 256 = 12288 frames per GPU), dealt round-robin to `--streams` independent pipelines, so
+that the driver's 20-step run keeps the GPU busy for well over a second.  The batches of a step cycle through `--groups` different
 frame sets (2048 distinct frames per GPU by default).
 
 One process per GPU; frames shard across ranks with no data-path collective, so scaling is weak: every rank runs
@@ -66,7 +66,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc")
     ap.add_argument("--batch", type=int, default=256, help="frames per batch (one launch sequence)")
-    ap.add_argument("--batches-per-step", type=int, default=32, help="batches per step: a step is batch * batches_per_step frames per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=48, help="batches per step: a step is batch * batches_per_step frames per GPU")
     ap.add_argument("--groups", type=int, default=8, help="distinct frame sets of `batch` frames resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (batches alternate)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (also skips verified_frames)")
