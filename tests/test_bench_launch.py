@@ -29,7 +29,7 @@ def test_gpus_2_spawns_two_ranks():
     # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 2 ms
     assert out["ms_per_step"] >= 4.0
     # whole-job value: both ranks' frames over the max time
-    assert abs(out["value"] - 2 * 256 * 32 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-3
+    assert abs(out["value"] - 2 * 256 * 48 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-3   # default step: 48 batches of 256 frames
 
 
 def test_gpus_1_is_a_single_process():
