@@ -134,7 +134,8 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
 #define WALK_MAX_N 2048
 enum { SCAN_AUTO = 0, SCAN_DENSE = 1, SCAN_WALK = 2 };
 
-// Workgroup-wide vote (all threads of a 256-thread workgroup must call it): true <=> pair p is served by k_match_walk.
+// Workgroup-wide vote (all NT threads of the workgroup must call it): true <=> pair p is served by k_match_walk.
+template <int NT = MATCH_NT>
 __device__ __forceinline__ bool pair_walks(const MatchProblemSet &M, int p, int n, int nq, int force, int *sVote /* one LDS word */) {
   if (force != SCAN_AUTO) return force == SCAN_WALK;
   if (n > WALK_MAX_N) return false;
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool pair_walks(const MatchProblemSet &M, int p, int 
   if (threadIdx.x == 0) *sVote = 0;
   __syncthreads();
   int big = 0;
-  for (int q = threadIdx.x; q < nq; q += MATCH_NT) {
+  for (int q = threadIdx.x; q < nq; q += NT) {
     const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
     const float u = M.qu[qo + q], v = M.qv[qo + q], r = M.qr[qo + q];
     const int cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w)), cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
@@ -932,23 +933,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   __shared__ int sRmin[4], sChg[4], sTake, sNm;   // sRmin / sChg: a ring over the rounds (see below)
   bool wide = false;
   if (WIDE_OK && !M.serial && !M.partner && M.couple == 0 && !M.qside && rforce != SCAN_DENSE) {
-    if (rforce == SCAN_WALK) wide = true;
-    else {   // pair_walks' vote with this kernel's block size
-      if (tid == 0) sVoteR = 0;
-      __syncthreads();
-      int big = n > WALK_MAX_N ? 1 : 0;
-      for (int q = tid; q < nq; q += WN) {
-        const uint8_t fl = M.qflags ? M.qflags[qo + q] : (uint8_t)3;
-        const float u = M.qu[qo + q], v = M.qv[qo + q], r = M.qr[qo + q];
-        const int cx0 = max(0, (int)floorf((u - M.min_x - r) * M.inv_w)), cx1 = min(63, (int)ceilf((u - M.min_x + r) * M.inv_w));
-        const int cy0 = max(0, (int)floorf((v - M.min_y - r) * M.inv_h)), cy1 = min(47, (int)ceilf((v - M.min_y + r) * M.inv_h));
-        const bool live = (fl & 1) && cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0;
-        if (live && (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > WALK_MAX_CELLS) big = 1;
-      }
-      if (big) sVoteR = 1;
-      __syncthreads();
-      wide = sVoteR == 0;
-    }
+    wide = pair_walks<WN>(M, p, n, nq, rforce, &sVoteR);   // k_match_walk's rule, voted by this kernel's 512 threads
   }
   if (wide) {
     if (tid == 0) { for (int i = 0; i < 4; i++) { sRmin[i] = 0x7fffffff; sChg[i] = 0; } sTake = 0; sNm = 0; }

@@ -1368,10 +1368,10 @@ static int search_host(orbm_t *m, const orbm_frame_t *f, const orbm_queries_t *q
   if (m->pin_bytes < total) {
     if (m->pin) (void)hipHostFree(m->pin);
     m->pin = nullptr; m->pin_bytes = 0;
-    MCHECK(m, hipHostMalloc(&m->pin, total + (total >> 2), hipHostMallocDefault));
-    m->pin_bytes = total + (total >> 2);
+    MCHECK(m, hipHostMalloc(&m->pin, 2 * total, hipHostMallocDefault));   // grown rarely: a re-allocation costs tens of milliseconds
+    m->pin_bytes = 2 * total;
   }
-  MCHECK(m, m->d_block.reserve(total + (total >> 2)));
+  MCHECK(m, m->d_block.reserve(m->d_block.bytes >= total ? total : 2 * total));
   uint8_t *hp = (uint8_t *)m->pin, *dp = (uint8_t *)m->d_block.p;
   for (const Part *p : {&pKp, &pDesc, &pUr, &pQd, &pQu, &pQv, &pQr, &pQur, &pMinl, &pMaxl, &pFl, &pPartner, &pSide, &pSlot, &pSobs})
     if (p->bytes) memcpy(hp + p->off, p->src, p->bytes);
@@ -1527,10 +1527,10 @@ int orbm_search_by_projection_last_frame(orbm_t *m, const orbm_frame_t *cur, con
   if (m->pin_bytes < total) {
     if (m->pin) (void)hipHostFree(m->pin);
     m->pin = nullptr; m->pin_bytes = 0;
-    MCHECK(m, hipHostMalloc(&m->pin, total + (total >> 2), hipHostMallocDefault));
-    m->pin_bytes = total + (total >> 2);
+    MCHECK(m, hipHostMalloc(&m->pin, 2 * total, hipHostMallocDefault));   // grown rarely: a re-allocation costs tens of milliseconds
+    m->pin_bytes = 2 * total;
   }
-  MCHECK(m, m->d_block.reserve(total + (total >> 2)));
+  MCHECK(m, m->d_block.reserve(m->d_block.bytes >= total ? total : 2 * total));
   uint8_t *hp = (uint8_t *)m->pin, *dp = (uint8_t *)m->d_block.p;
   for (const Part *p : {&pKp, &pDesc, &pUr, &pHas, &pXw, &pMd, &pLk, &pObs, &pTc, &pTl, &pSlot, &pSobs})
     if (p->bytes) memcpy(hp + p->off, p->src, p->bytes);
