@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     return;
   }
 #ifdef RESOLVE_STAMPS
-  long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0;
+  long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0, t_sub[6] = {0, 0, 0, 0, 0, 0}, sub_m = 0;
   long long t0 = __builtin_readcyclecounter();
 #endif
   if (wid != 0) {
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       // refresh the lists of the lanes in F, RESOLVE_NW per pass (one wavefront each)
       auto refresh = [&](unsigned long long F) {
 #ifdef RESOLVE_STAMPS
-        long long ts0 = __builtin_readcyclecounter();
+        long long ts0 = __builtin_readcyclecounter(), ts1 = ts0;
 #endif
         const bool mineF = (F >> lane) & 1ull;
         unsigned long long todo = F;
@@ -1185,10 +1185,22 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           }
           const int m = min(RESOLVE_NW, (int)__popcll(todo));
           if (lane == 0) sCmd = m;
+#ifdef RESOLVE_STAMPS
+          long long tq = __builtin_readcyclecounter(); t_sub[0] += tq - ts1; ts1 = tq; sub_m += m;
+#endif
           __syncthreads();             // (A)
+#ifdef RESOLVE_STAMPS
+          tq = __builtin_readcyclecounter(); t_sub[1] += tq - ts1; ts1 = tq;
+#endif
           const int np = shares_of(m);
           serve(0, 0, np);
+#ifdef RESOLVE_STAMPS
+          tq = __builtin_readcyclecounter(); t_sub[2] += tq - ts1; ts1 = tq;
+#endif
           __syncthreads();             // (B)
+#ifdef RESOLVE_STAMPS
+          tq = __builtin_readcyclecounter(); t_sub[3] += tq - ts1; ts1 = tq;
+#endif
           if (take) {
             // merge the np sorted shares of my request: min(A[i], B[K-1-i]) are the K smallest of a pair's union (a bitonic
             // sequence), two compare-exchange stages sort them; the rest of my column is empty
@@ -1212,11 +1224,13 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           todo &= ~__ballot(take);
 #ifdef RESOLVE_STAMPS
           n_batch++;
+          tq = __builtin_readcyclecounter(); t_sub[4] += tq - ts1; ts1 = tq;
 #endif
         }
         if (mineF) capm1 = REFRESH_K - 1;
         load_list();
 #ifdef RESOLVE_STAMPS
+        t_sub[5] += __builtin_readcyclecounter() - ts1;
         t_refresh += __builtin_readcyclecounter() - ts0; n_refresh += __popcll(F);
 #endif
       };
@@ -1321,7 +1335,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       }
     }
 #ifdef RESOLVE_STAMPS
-    if (lane == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)p; d[0] = n_batch; d[1] = t_chunk; d[2] = t_round; d[3] = t_refresh; d[4] = n_refresh; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; d[7] = n_round; }
+    if (lane == 0 && M.dbg) { long long *d = M.dbg + 16 * (size_t)p; d[0] = n_batch; d[1] = t_chunk; d[2] = t_round; d[3] = t_refresh; d[4] = n_refresh; d[5] = __builtin_readcyclecounter() - t0; d[6] = nq; d[7] = n_round; for (int i = 0; i < 6; i++) d[8 + i] = t_sub[i]; d[14] = sub_m; }
 #endif
     if (lane == 0) { sCmd = -1; if (M.nmatches) M.nmatches[p] = nmatches; }
     __syncthreads();                   // (A) exit command

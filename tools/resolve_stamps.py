@@ -31,7 +31,7 @@ if "--tracking" in sys.argv:   # windows of a tracking search: radius 15 * scale
     rad = (15.0 * sf[octv.long()]).contiguous(); lvl = (octv - 1).contiguous(); lvl_hi = (octv + 1).contiguous()
 slot = torch.full((B, cap), -1, dtype=torch.int32, device=dev); sobs = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
 moq = torch.empty((B, cap), dtype=torch.int32, device=dev); nm = torch.zeros((B,), dtype=torch.int32, device=dev)
-dbg = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+dbg = torch.zeros((B, 16), dtype=torch.int64, device=dev)
 os.environ["ORBHIP_DBG_PTR"] = str(dbg.data_ptr())
 fs = pkg.FrameStruct(cap, d_kps[1:].data_ptr(), d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
 qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), rad.data_ptr(), lvl.data_ptr(), lvl_hi.data_ptr(), None, None)
@@ -40,7 +40,8 @@ rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(fs), cap, C.c_voi
                                                  C.c_void_p(nm.data_ptr()), None)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
-names = ["refresh_batches", "chunk_setup", "rounds+commit", "refreshes", "n_refreshed", "total", "nq", "n_round"]
+names = ["refresh_batches", "chunk_setup", "rounds+commit", "refreshes", "n_refreshed", "total", "nq", "n_round",
+         "refresh: post requests", "refresh: barrier A", "refresh: serve", "refresh: barrier B", "refresh: merge", "refresh: reload list", "requests served"]
 m = d.mean(axis=0)
 for n, x in zip(names, m): print("%-18s %12.0f" % (n, x))
 print("cycles per round: %.0f   per refresh batch: %.0f   rounds per query: %.2f" % (m[2] / max(m[7], 1), m[3] / max(m[0], 1), m[7] / m[6]))
