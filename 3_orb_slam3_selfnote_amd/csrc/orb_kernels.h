@@ -412,7 +412,6 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ __align__(16) uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[4 * FAST_LIST_SEG];
-  __shared__ uint32_t sKept[900];   // strict 3x3 maxima: at most ceil(cw/2) * ceil(ch/2) <= 30 * 30
   __shared__ __align__(16) uint32_t sWCount[12];   // [0..3] pass-1 list segments, [4..11] two count buffers of the ordered compactions
   const int tid = threadIdx.x, lane = tid & 63;
   int cellId, frame;
@@ -476,6 +475,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   const bool xin = px < cw;
   uint16_t *myList = sList + wave * FAST_LIST_SEG;
   uint32_t *sCnt2 = sWCount + 4;   // [2][4]
+  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
   int turn = 0, nkept = 0;
   int t = P.iniTh;
   for (int detection = 0;; detection++) {
@@ -539,10 +539,11 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     }
     __syncthreads();
     FSTAMP(2);
-    // ---- pass 3 (survivors only): S > t and 3x3 strict maximum inside the cell -> kept list in raster order.
-    // Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.  Order-preserving compaction of
+    // ---- pass 3 (survivors only): S > t and 3x3 strict maximum inside the cell; cv::FAST emits rows ascending, x ascending = the
+    // list's own order, so a kept entry's output slot is its rank among the kept ones and it is written on the spot.
+    // Non-survivors have score 0 in the plane, exactly what cv::FAST's NMS sees for non-corners.  Order-preserving ranks of
     // each 256-entry chunk: a ballot + lane rank inside a wavefront, the four wavefronts' counts through LDS - two count
-    // buffers in turn, so one barrier per chunk.  No atomics, no sorting afterwards.
+    // buffers in turn, so one barrier per chunk.  No atomics, no sorting afterwards, no kept list.
     for (int e0 = 0; e0 < nlist; e0 += FAST_NT) {
       const int e = e0 + tid;
       bool keep = false;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
         const int m1 = max(max((int)s[FAST_S_PITCH - 1], (int)s[FAST_S_PITCH]), (int)s[FAST_S_PITCH + 1]);
         const int m2 = max(max((int)s[-1], (int)s[1]), max(m0, m1));
         keep = (S > t) & (S >= 2) & (S > m2);
-        kv = (uint32_t)p | ((uint32_t)S << 12);
+        kv = ((uint32_t)(S - 1) << 24) | ((baseY + (uint32_t)y + 3u) << 12) | (baseX + (uint32_t)x + 3u);
       }
       const unsigned long long bK = __builtin_amdgcn_ballot_w64(keep);
       uint32_t *cnt = sCnt2 + 4 * turn;
@@ -565,25 +566,17 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
       __syncthreads();
       const uint4 c4 = *reinterpret_cast<const uint4 *>(cnt);
       const uint32_t pre = (wave > 0 ? c4.x : 0u) + (wave > 1 ? c4.y : 0u) + (wave > 2 ? c4.z : 0u);
-      if (keep) sKept[nkept + (int)pre + lane_rank(bK)] = kv;               // <= ceil(cw/2)*ceil(ch/2) <= 900 entries
+      const uint32_t rank = (uint32_t)nkept + pre + (uint32_t)lane_rank(bK);
+      if (keep && rank < cellCap) slots[rank] = kv;
       nkept += (int)(c4.x + c4.y + c4.z + c4.w);
     }
-    __syncthreads();
     FSTAMP(3);
     // ORBextractor.cc:825: the second detection runs only if the first returned nothing (with minThFAST >= iniThFAST it could
     // only return a subset of nothing)
     if (nkept > 0 || detection == 1 || P.minTh >= P.iniTh) break;
     t = P.minTh;
   }
-  // ---- pass 4: cv::FAST emits rows ascending, x ascending = the kept list's own order: every keypoint goes to its rank.
-  uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + r0.w;
-  const int nout = min(nkept, (int)cellCap);
-  for (int e = tid; e < nout; e += FAST_NT) {
-    const uint32_t v = sKept[e], S = (v >> 12) & 255u;
-    const uint32_t X = baseX + (v & 63u) + 3u, Y = baseY + ((v >> 6) & 63u) + 3u;
-    slots[e] = ((S - 1u) << 24) | (Y << 12) | X;
-  }
-  if (tid == 0) *cellCnt = (uint32_t)nout;
+  if (tid == 0) *cellCnt = (uint32_t)min(nkept, (int)cellCap);
   FSTAMP(7);
 }
 

@@ -30,7 +30,7 @@ for it in range(3):
     torch.cuda.synchronize()
 v = buf.cpu().numpy().astype(np.float64)
 live = v[:, 0] > 0
-names = ["prologue+tile load", "pass1 compass+list", "pass2 score", "pass3 NMS", "threshold filter", "(unused)", "(unused)", "pass4 rank+emit"]
+names = ["prologue+tile load", "pass1 compass+list", "pass2 score", "pass3 NMS + emit", "(unused)", "(unused)", "(unused)", "cell count"]
 m = v[live].mean(axis=0)
 for n, x in zip(names, m):
     print("%-22s %6.1f %%   %.0f cycles/workgroup" % (n, 100 * x / m.sum(), x))
