@@ -275,13 +275,14 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
         // Every live lane's window contains the whole grid and has no level filter (BASELINE's 1000x1000 stress setting, or a
         // relocalisation-style wide search): GetFeaturesInArea returns every in-grid keypoint, so the only test left is the
         // candidate's own usable bit, which is the same for all lanes (a scalar branch).
-        // The candidate is the same for all 64 lanes: its descriptor comes through the scalar cache into SGPRs (the LDS copy
-        // costs two 1-KiB broadcast reads per candidate and wavefront, and the LDS pipe is shared by the CU's 16 wavefronts).
-        // Four candidates per trip, nothing conditional in front of their distances: four scalar loads in flight together (one
-        // candidate at a time left each wavefront waiting out its own load), and ONE vote per trip on "does any of the four
+        // Four candidates per trip, nothing conditional in front of their distances: eight LDS broadcast reads in flight together
+        // (one candidate at a time left each wavefront waiting out its own reads), and ONE vote per trip on "does any of the four
         // enter some lane's list" - after the first few hundred candidates it hardly ever does.  19 vector instructions per
-        // candidate and wavefront (8 xor with a scalar operand, 8 accumulating popcounts, 3 for the key); tools/scan_stamps.py.
-        const int baseu = __builtin_amdgcn_readfirstlane(base), nu = __builtin_amdgcn_readfirstlane(n);
+        // candidate and wavefront (8 xor, 8 accumulating popcounts, 3 for the key); tools/scan_stamps.py.  The descriptors are
+        // the same for all 64 lanes and could come through the scalar cache into SGPRs instead (tried: s_load_dwordx8 x 4 per
+        // trip), but a vector instruction that reads a scalar register issues at the half rate (profiles/valu_calib.json), which
+        // costs the eight xors more than the LDS reads do: 0.262 ms against 0.238.
+        const int baseu = __builtin_amdgcn_readfirstlane(base);
         auto hamming = [&](const uint4 a, const uint4 b) {
           int d0 = popc_acc(a.x ^ qd[0], 0), d1 = popc_acc(b.x ^ qd[4], 0);
           d0 = popc_acc(a.y ^ qd[1], d0); d1 = popc_acc(b.y ^ qd[5], d1);
@@ -305,21 +306,11 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
           }
         };
         for (int c = 0; c < m4u; c += 4) {
-          // (entries past the chunk's last candidate are unusable, bits = 0; their loads are clamped to the frame's last descriptor)
-          const int i0 = min(baseu + c, nu - 1), i1 = min(baseu + c + 1, nu - 1), i2 = min(baseu + c + 2, nu - 1), i3 = min(baseu + c + 3, nu - 1);
-          // (written as instructions: the compiler sinks a scalar load next to its first use and waits for each on its own)
-          typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-          u32x8 D0, D1, D2, D3;
-          asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx8 %2, %6, 0x0\n\ts_load_dwordx8 %3, %7, 0x0"
-                       : "=&s"(D0), "=&s"(D1), "=&s"(D2), "=&s"(D3)
-                       : "s"(desc + (size_t)i0 * 2), "s"(desc + (size_t)i1 * 2), "s"(desc + (size_t)i2 * 2), "s"(desc + (size_t)i3 * 2));
+          // (entries past the chunk's last candidate are unusable, bits = 0: whatever their LDS rows hold yields the key NONE)
+          const uint4 a0 = sDesc[2 * c], b0 = sDesc[2 * c + 1], a1 = sDesc[2 * c + 2], b1 = sDesc[2 * c + 3];
+          const uint4 a2 = sDesc[2 * c + 4], b2 = sDesc[2 * c + 5], a3 = sDesc[2 * c + 6], b3 = sDesc[2 * c + 7];
           const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c].bits), s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 1].bits);
           const uint32_t s2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 2].bits), s3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sMeta[c + 3].bits);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(D0), "+s"(D1), "+s"(D2), "+s"(D3));
-          const uint4 a0 = make_uint4(D0[0], D0[1], D0[2], D0[3]), b0 = make_uint4(D0[4], D0[5], D0[6], D0[7]);
-          const uint4 a1 = make_uint4(D1[0], D1[1], D1[2], D1[3]), b1 = make_uint4(D1[4], D1[5], D1[6], D1[7]);
-          const uint4 a2 = make_uint4(D2[0], D2[1], D2[2], D2[3]), b2 = make_uint4(D2[4], D2[5], D2[6], D2[7]);
-          const uint4 a3 = make_uint4(D3[0], D3[1], D3[2], D3[3]), b3 = make_uint4(D3[4], D3[5], D3[6], D3[7]);
           const K t0 = key_of(hamming(a0, b0), s0, baseu + c), t1 = key_of(hamming(a1, b1), s1, baseu + c + 1);
           const K t2 = key_of(hamming(a2, b2), s2, baseu + c + 2), t3 = key_of(hamming(a3, b3), s3, baseu + c + 3);
           const K tmin = min(min(t0, t1), min(t2, t3));
