@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
-    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_set_profiling", "orbm_set_scan_mode", "orbm_get_last_ms", "orbm_get_stage_ms",
+    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_undistort_keypoints_batch_device", "orbm_set_profiling", "orbm_set_scan_mode", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
 
@@ -163,6 +163,7 @@ def load(build_if_needed=True):
     L.orbm_project.argtypes = [i32, vp, f32, f32, f32, vp, vp]
     L.orbm_undistort_keypoints.argtypes = [i32, vp, vp, vp, i32, vp]
     L.orbm_image_bounds.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp, vp]
+    L.orbm_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp]
     L.orbm_set_profiling.argtypes = [vp, i32]
     L.orbm_set_scan_mode.argtypes = [vp, i32]
     L.orbm_set_scan_mode.restype = i32
@@ -775,6 +776,16 @@ class ORBmatcher:
         d = np.zeros((len(q), len(c)), dtype=np.uint16)
         self._check(self.L.orbm_hamming_matrix(self.m, _p(q), len(q), _p(c), len(c), _p(d)), "orbm_hamming_matrix")
         return d
+
+    def undistort_batch_device(self, d_keys, key_stride, d_counts, count_stride, nframes, K, D, d_keys_un, stream=None, n_const=0):
+        """Frame::UndistortKeyPoints (Frame.cc:837-870) on keypoints resident in HBM; pointers are device addresses (ints)."""
+        K, D = np.ascontiguousarray(K, dtype=np.float32), np.ascontiguousarray(D, dtype=np.float32)
+        rc = self.L.orbm_undistort_keypoints_batch_device(self.m, C.c_void_p(d_keys), int(key_stride), C.c_void_p(d_counts) if d_counts else None,
+                                                          int(count_stride), int(n_const), int(nframes), _p(K), _p(D), len(D), C.c_void_p(d_keys_un),
+                                                          C.c_void_p(stream) if stream else None)
+        self._check(rc, "orbm_undistort_keypoints_batch_device")
+        if rc < 0:
+            raise OrbError("orbm_undistort_keypoints_batch_device rc=%d" % rc)
 
     def set_profiling(self, on=True):
         self.L.orbm_set_profiling(self.m, 1 if on else 0)

@@ -173,3 +173,48 @@ __global__ __launch_bounds__(256) void k_rot_prune(RotPruneParams R) {
   __syncthreads();
   if (t == 0 && removed) R.nmatches[p] -= removed;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// G0: Frame::UndistortKeyPoints (Frame.cc:837-870) for frames resident in HBM - the step between operator() and the
+// searches in the Frame constructor.  cv::undistortPoints(pts, K, D, R = I, P = K) restated: five
+// fixed-point iterations in double, every operation in source order (no contraction; fp64 division and the
+// double -> float conversions are IEEE on gfx950), i.e. the same bits as the host function orbm_undistort_keypoints,
+// which tests/test_gpu_distort.py checks.  One thread per keypoint; only pt changes (:862-868).
+// ------------------------------------------------------------------------------------------------------------
+struct UndistortParams {
+  const float *keys;           // orbx_keypoint_t AoS viewed as floats, frame f at element offset f * key_stride
+  float *keys_un;              // may alias keys
+  int key_stride;
+  const int32_t *counts; int count_stride; int count_const;
+  float K[4], D[5]; int nD;
+};
+
+__host__ __device__ __forceinline__ void undistort_point(double u, double v, const float *K, const float *D, int nD, float *ou, float *ov) {
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = nD > 4 ? D[4] : 0.0;
+  double x = (u - cx) * (1. / fx), y = (v - cy) * (1. / fy);
+  const double x0 = x, y0 = y;
+  for (int it = 0; it < 5; it++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+    const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+    const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  *ou = (float)(x * fx + cx);
+  *ov = (float)(y * fy + cy);
+}
+
+__global__ __launch_bounds__(256) void k_undistort(UndistortParams U) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int n = U.counts ? U.counts[(size_t)f * U.count_stride] : U.count_const;
+  if (i >= n) return;
+  const size_t o = ((size_t)f * U.key_stride + i) * 7;
+  float k[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++) k[t] = U.keys[o + t];
+  if (U.D[0] != 0.0f) undistort_point((double)k[0], (double)k[1], U.K, U.D, U.nD, &k[0], &k[1]);   // :839-843: D[0] == 0 copies
+#pragma unroll
+  for (int t = 0; t < 7; t++) U.keys_un[o + t] = k[t];
+}

@@ -1151,23 +1151,9 @@ void orbm_three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3)
 
 float orbm_radius_by_viewing_cos(float viewCos) { return ((double)viewCos > 0.998) ? 2.5f : 4.0f; }  // ORBmatcher.cc:216-222
 
-// cv::undistortPoints with R = I, P = K (Frame.cc:856, :883): 5 fixed-point iterations in double
-static void undistort_one(double u, double v, const float *K, const float *D, int nD, float *ou, float *ov) {
-  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
-  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = nD > 4 ? D[4] : 0.0;
-  double x = (u - cx) * (1. / fx), y = (v - cy) * (1. / fy);
-  const double x0 = x, y0 = y;
-  for (int it = 0; it < 5; it++) {
-    const double r2 = x * x + y * y;
-    const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
-    const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
-    const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
-    x = (x0 - dx) * icdist;
-    y = (y0 - dy) * icdist;
-  }
-  *ou = (float)(x * fx + cx);
-  *ov = (float)(y * fy + cy);
-}
+// cv::undistortPoints with R = I, P = K (Frame.cc:856, :883): 5 fixed-point iterations in double; one source
+// for the host functions below and k_undistort (orb_project_kernels.h)
+static void undistort_one(double u, double v, const float *K, const float *D, int nD, float *ou, float *ov) { undistort_point(u, v, K, D, nD, ou, ov); }
 
 void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K, const float *D, int nD, orbx_keypoint_t *keys_un) {
   if (!keys || !keys_un || !K || !D) return;
@@ -1191,6 +1177,25 @@ void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int n
   } else {
     *min_x = 0.0f; *max_x = (float)cols; *min_y = 0.0f; *max_y = (float)rows;
   }
+}
+
+int orbm_undistort_keypoints_batch_device(orbm_t *m, const orbx_keypoint_t *d_keys, int key_stride, const int32_t *d_counts, int count_stride,
+                                          int n_const, int nframes, const float *K, const float *D, int nD, orbx_keypoint_t *d_keys_un, void *stream_) {
+  if (!m || !d_keys || !d_keys_un || !K || !D || nframes <= 0 || key_stride <= 0 || (nD != 4 && nD != 5)) return ORBX_E_ARG;
+  if (!d_counts && (n_const < 0 || n_const > key_stride)) return ORBX_E_ARG;
+  MCHECK(m, hipSetDevice(m->device));
+  UndistortParams U;
+  memset(&U, 0, sizeof(U));
+  U.keys = reinterpret_cast<const float *>(d_keys); U.keys_un = reinterpret_cast<float *>(d_keys_un); U.key_stride = key_stride;
+  U.counts = d_counts; U.count_stride = count_stride; U.count_const = n_const;
+  for (int i = 0; i < 4; i++) U.K[i] = K[i];
+  for (int i = 0; i < nD; i++) U.D[i] = D[i];
+  U.nD = nD;
+  const int maxn = d_counts ? key_stride : n_const;
+  if (maxn == 0) return 0;
+  hipLaunchKernelGGL(k_undistort, dim3((maxn + 255) / 256, nframes), dim3(256), 0, (hipStream_t)stream_, U);
+  MCHECK(m, hipGetLastError());
+  return 0;
 }
 
 void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float *u, float *v) {

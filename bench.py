@@ -57,6 +57,8 @@ CONFIGS = {
                   metric="frames/sec ORB extract+match, 512x512 KannalaBrandt8"),
 }
 TUMVI_TH = 15.0         # Tracking.cc:2898: th = 15 for monocular frames
+EUROC_K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)                    # Examples/Monocular/EuRoC.yaml:9-12
+EUROC_D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)    # EuRoC.yaml:14-17
 
 
 def parse_args(argv):
@@ -72,6 +74,9 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (also skips verified_frames)")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE configs[1])")
+    ap.add_argument("--distort", choices=["auto", "none", "euroc"], default="auto",
+                    help="euroc: Frame::UndistortKeyPoints with the EuRoC.yaml:9-17 calibration between extraction and search, grid on the "
+                         "undistorted-corner bounds (Frame.cc:837-899) - what the reference does on this configuration; auto = euroc for --config euroc")
     return ap.parse_args(argv)
 
 
@@ -124,7 +129,7 @@ def stats_ms(a):
     return {"median": round(float(np.median(a)), 3), "mean": round(float(a.mean()), 3)}
 
 
-def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads):
+def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=None):
     """BASELINE.md section 3 over the oracle (native driver, oracle/orb_cpu_bench.c) + the parity tie of the timed region:
     one core over the frame set the GPU's last timed batch worked on (every frame compared), all cores over every resident set."""
     from oracle import oracle_py as O
@@ -140,7 +145,7 @@ def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads):
 
     frames, offs = groups[g_last]
     B = len(frames)
-    r1 = O.bench_stream(ex, frames, offs, B, threads=1, warmup=50, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100, scene=scene_of(g_last))
+    r1 = O.bench_stream(ex, frames, offs, B, threads=1, warmup=50, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100, scene=scene_of(g_last), distort=distort)
     # ---- parity tie: the last timed batch of the GPU against the oracle, frame by frame
     bad = []
     verified = 0
@@ -164,7 +169,7 @@ def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads):
     for g in range(len(groups)):
         fr, of = groups[g]
         ra = O.bench_stream(ex, fr, of, len(fr), threads=nthreads, warmup=nthreads if g == 0 else 0, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100,
-                            scene=scene_of(g))
+                            scene=scene_of(g), distort=distort)
         nfr += len(fr); we += ra["wall_extract"]; wm += ra["wall_match"]
     allc = {"threads": nthreads, "frames": nfr, "fps": round(nfr / (we + wm), 3), "extract_fps": round(nfr / we, 3), "match_fps": round(nfr / wm, 3)}
     out = {"value": one["fps"], "unit": "frames/s", "cores": 1, "kind": "port",
@@ -217,6 +222,8 @@ def main():
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
     C = pkg.C
     tumvi = args.config == "tumvi"
+    distort = (args.distort == "euroc" or (args.distort == "auto" and not tumvi)) and not tumvi and not args.no_match
+    bounds = pkg.image_bounds(W, H, EUROC_K, EUROC_D) if distort else (0.0, float(W), 0.0, float(H))
 
     # ---- resident inputs: G frame sets of B frames each (distinct crops of G moving synthetic scenes)
     groups = [synth.make_stream(1000 + 64 * rank + g, B, H, W) for g in range(G)]
@@ -246,7 +253,9 @@ def main():
             self.d_sobs = torch.empty((B, cap), dtype=torch.uint8, device=dev)
             self.d_moq = torch.empty((B, cap), dtype=torch.int32, device=dev)
             self.d_nm = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.fs = pkg.FrameStruct(cap, self.d_kps[1:].data_ptr(), self.d_desc[1:].data_ptr(), None, 0.0, float(W), 0.0, float(H))
+            # mvKeysUn (Frame.cc:837-870): a second keypoint block when the calibration has distortion, else mvKeysUn = mvKeys
+            self.d_kps_un = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev) if distort else self.d_kps
+            self.fs = pkg.FrameStruct(cap, self.d_kps_un[1:].data_ptr(), self.d_desc[1:].data_ptr(), None, *bounds)
             self.group = -1
 
         def batch(self, g, images=None, scene=None):
@@ -259,13 +268,17 @@ def main():
                 ex.extract_batch_device(img.data_ptr(), H, W, W, H * W, B, d_kps[1:].data_ptr(), d_desc[1:].data_ptr(), d_cnt[1:].data_ptr(), cap, LAP, stream=stream)
                 if args.no_match:
                     return
+                d_kun = self.d_kps_un
+                if distort:   # the Frame constructor's UndistortKeyPoints for the B frames of the batch
+                    mt.undistort_batch_device(d_kps[1:].data_ptr(), cap, d_cnt[1:].data_ptr(), 2, B, EUROC_K, EUROC_D, d_kun[1:].data_ptr(), stream=stream)
+                    d_kun[0].copy_(d_kun[B])
                 # the set's last frame is the predecessor of its first (60 KB device copy)
                 d_kps[0].copy_(d_kps[B]); d_desc[0].copy_(d_desc[B]); d_cnt[0].copy_(d_cnt[B])
                 self.d_slot.fill_(-1); self.d_sobs.zero_()                  # Frame ctor: mvpMapPoints = NULL
                 if not tumvi:
                     # caller-side projection of the previous frame's features into the current frame (pure shift in this stream)
-                    u = (d_kps[:B, :, 0] + d_shift[g][:, 0:1]).contiguous()
-                    v = (d_kps[:B, :, 1] + d_shift[g][:, 1:2]).contiguous()
+                    u = (d_kun[:B, :, 0] + d_shift[g][:, 0:1]).contiguous()
+                    v = (d_kun[:B, :, 1] + d_shift[g][:, 1:2]).contiguous()
                     qs = pkg.QueryStruct(cap, d_desc.data_ptr(), u.data_ptr(), v.data_ptr(), self.d_radius.data_ptr(), self.d_lvl.data_ptr(), self.d_lvl.data_ptr(), None, None)
                     rc = mt.L.orbm_search_by_projection_batch_device(mt.m, C.byref(self.fs), cap, C.c_void_p(d_cnt[1:].data_ptr()), 2, C.byref(qs), cap,
                                                                      C.c_void_p(d_cnt.data_ptr()), 2, B, C.c_float(0.8), 100, 1,
@@ -495,6 +508,8 @@ def main():
             "config": {"workload": conf["workload"], "image": "%dx%d" % (W, H), "nfeatures": CFG["nfeatures"], "nlevels": CFG["nlevels"],
                        "frames_per_step_per_gpu": frames_per_step, "batch": B, "batches_per_step": NB, "distinct_frames_per_gpu": G * B, "streams": S,
                        "mean_keypoints_per_frame": round(n_kp, 1), "mean_matches_per_frame": round(nm_mean, 1),
+                       "frame_geometry": ("EuRoC.yaml:9-17 calibration: keypoints undistorted per batch on the device, grid bounds = undistorted corners "
+                                          "(%.2f, %.2f, %.2f, %.2f)" % bounds) if distort else "no distortion: bounds = image rectangle",
                        "sharding": "frames round-robin, one process per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -513,7 +528,7 @@ def main():
             out["host_fed"] = host_fed
         if gpu_last is not None:
             nthreads = host_cores()
-            cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads)
+            cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=(EUROC_K, EUROC_D) if distort else None)
             out["cpu_baseline"] = cb
             out["verified_frames"] = verified
             out["verified_of"] = B

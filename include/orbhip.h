@@ -480,6 +480,13 @@ void orbm_project(int cam_type, const float *params, float X, float Y, float Z, 
 void orbm_undistort_keypoints(int n, const orbx_keypoint_t *keys, const float *K, const float *D, int nD, orbx_keypoint_t *keys_un);
 void orbm_image_bounds(int cols, int rows, const float *K, const float *D, int nD, float *min_x, float *max_x, float *min_y,
                        float *max_y);
+/* Frame::UndistortKeyPoints (Frame.cc:837-870) for `nframes` frames whose keypoints are resident in HBM (the output of
+ * orbx_extract_batch_device): frame f's keypoints at d_keys + f * key_stride, its count at d_counts[f * count_stride]
+ * (d_counts == NULL: n_const keypoints per frame).  Same arithmetic, same bits as orbm_undistort_keypoints (one source,
+ * csrc/orb_project_kernels.h).  d_keys_un may alias d_keys.  Asynchronous on `stream`; returns 0 or an ORBX_E_* code. */
+int orbm_undistort_keypoints_batch_device(orbm_t *m, const orbx_keypoint_t *d_keys, int key_stride, const int32_t *d_counts,
+                                          int count_stride, int n_const, int nframes, const float *K, const float *D, int nD,
+                                          orbx_keypoint_t *d_keys_un, void *stream);
 
 /* How the projection searches enumerate a query's candidates.  The reference walks the grid cells of the query's window
  * (Frame::GetFeaturesInArea, Frame.cc:744-813); on the device that is k_match_walk, right for tracking-sized windows, while

@@ -546,10 +546,11 @@ class BenchCfg(C.Structure):  # orc_bench_cfg (orb_cpu_bench.c)
     _fields_ = [("nframes", C.c_int), ("count", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("threads", C.c_int), ("warmup", C.c_int),
                 ("lap0", C.c_int), ("lap1", C.c_int), ("cap", C.c_int), ("mode", C.c_int), ("nnratio", C.c_float), ("th_high", C.c_int),
                 ("cam_type", C.c_int), ("cam", C.c_void_p), ("Xw", C.c_void_p), ("has_mp", C.c_void_p), ("Tcw", C.c_void_p), ("Tlw", C.c_void_p),
-                ("th", C.c_float), ("check_ori", C.c_int), ("bounds", C.c_float * 4)]
+                ("th", C.c_float), ("check_ori", C.c_int), ("bounds", C.c_float * 4),
+                ("distort", C.c_int), ("K", C.c_float * 4), ("D", C.c_float * 5), ("nD", C.c_int)]
 
 
-def bench_stream(ex, frames, offs, count, threads=1, warmup=50, lap=(0, 1000), cap=None, mode=0, nnratio=0.8, th_high=100, scene=None):
+def bench_stream(ex, frames, offs, count, threads=1, warmup=50, lap=(0, 1000), cap=None, mode=0, nnratio=0.8, th_high=100, scene=None, distort=None):
     """BASELINE.md section 3 protocol over the oracle, natively timed (orb_cpu_bench.c): frames [n, H, W] uint8, offs [n, 2] int32.
     mode 0 = extract + config-3 stress match; mode 1 = extract + last-frame search with `scene` = dict(cam_type, cam, Xw [n, cap, 3],
     has_mp [n, cap], Tcw [n, 16], Tlw [n, 16], th, check_ori, bounds).  Returns a dict with the per-frame outputs and times."""
@@ -563,6 +564,13 @@ def bench_stream(ex, frames, offs, count, threads=1, warmup=50, lap=(0, 1000), c
     cfg.nframes, cfg.count, cfg.rows, cfg.cols, cfg.threads, cfg.warmup = n, int(count), H, W, int(threads), int(warmup)
     cfg.lap0, cfg.lap1, cfg.cap, cfg.mode, cfg.nnratio, cfg.th_high = int(lap[0]), int(lap[1]), int(cap), int(mode), float(nnratio), int(th_high)
     keep = []
+    if distort is not None:   # (K[4], D[4 or 5]): mode 0 on undistorted keypoints with the undistorted-corner bounds (Frame.cc:837-899)
+        Kd, Dd = distort
+        cfg.distort, cfg.nD = 1, len(Dd)
+        for i in range(4):
+            cfg.K[i] = float(Kd[i])
+        for i in range(len(Dd)):
+            cfg.D[i] = float(Dd[i])
     if mode == 1:
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
         cam, Xw, has, Tcw, Tlw = a(scene["cam"], np.float32), a(scene["Xw"], np.float32), a(scene["has_mp"], np.uint8), a(scene["Tcw"], np.float32), a(scene["Tlw"], np.float32)

@@ -42,6 +42,11 @@ typedef struct {
   float th;
   int check_ori;
   float bounds[4];        /* mnMinX, mnMaxX, mnMinY, mnMaxY of the current frame */
+  /* mode 0 with distortion (the EuRoC calibration is pinhole + radial-tangential, EuRoC.yaml:9-17): the Frame constructor's
+   * UndistortKeyPoints / ComputeImageBounds (Frame.cc:837-899) run between extraction and search, the grid and the search work on
+   * mvKeysUn, and the projected features of the last frame are its undistorted keypoints plus the stream's shift */
+  int distort;            /* 0: mvKeysUn = mvKeys, bounds = image rectangle */
+  float K[4], D[5]; int nD;
 } orc_bench_cfg;
 
 typedef struct {
@@ -91,12 +96,26 @@ static void match_one(job_t *J, int t) {
   /* the Frame constructor's share that the matcher needs: keypoint SoA + the 64x48 grid (Frame.cc:434-465) */
   for (int i = 0; i < n1; i++) { kx[i] = k1[i].x; ky[i] = k1[i].y; oct[i] = k1[i].octave; ang[i] = k1[i].angle; slot[i] = -1; }
   orc_frame F;
-  if (c->mode == 0) orc_frame_init(&F, n1, kx, ky, oct, ang, d1, NULL, 0.0f, (float)c->cols, 0.0f, (float)c->rows, J->e->mvScaleFactor, J->e->nlevels);
+  float *xy = NULL;
+  if (c->mode == 0 && c->distort) {   /* Frame.cc:837-870 (current frame), :872-899 */
+    xy = (float *)malloc(sizeof(float) * 4 * (size_t)(m + 1));
+    for (int i = 0; i < n1; i++) { xy[2 * i] = k1[i].x; xy[2 * i + 1] = k1[i].y; }
+    orc_undistort_points(n1, xy, c->K, c->D, c->nD, xy + 2 * (size_t)(m + 1));
+    for (int i = 0; i < n1; i++) { kx[i] = xy[2 * (size_t)(m + 1) + 2 * i]; ky[i] = xy[2 * (size_t)(m + 1) + 2 * i + 1]; }
+    float b[4];
+    orc_image_bounds(c->cols, c->rows, c->K, c->D, c->nD, &b[0], &b[1], &b[2], &b[3]);
+    orc_frame_init(&F, n1, kx, ky, oct, ang, d1, NULL, b[0], b[1], b[2], b[3], J->e->mvScaleFactor, J->e->nlevels);
+  } else if (c->mode == 0) orc_frame_init(&F, n1, kx, ky, oct, ang, d1, NULL, 0.0f, (float)c->cols, 0.0f, (float)c->rows, J->e->mvScaleFactor, J->e->nlevels);
   else orc_frame_init(&F, n1, kx, ky, oct, ang, d1, NULL, c->bounds[0], c->bounds[1], c->bounds[2], c->bounds[3], J->e->mvScaleFactor, J->e->nlevels);
   int nm = 0;
   if (n1 > 0 && n0 > 0) {
     if (c->mode == 0) {
       const float sx = (float)(J->offs[2 * tl] - J->offs[2 * t]), sy = (float)(J->offs[2 * tl + 1] - J->offs[2 * t + 1]);
+      if (c->distort) {   /* the last frame's mvKeysUn (computed by ITS constructor in the reference; timed here with the pair) */
+        for (int i = 0; i < n0; i++) { xy[2 * i] = k0[i].x; xy[2 * i + 1] = k0[i].y; }
+        orc_undistort_points(n0, xy, c->K, c->D, c->nD, xy + 2 * (size_t)(m + 1));
+        for (int i = 0; i < n0; i++) { u[i] = xy[2 * (size_t)(m + 1) + 2 * i] + sx; v[i] = xy[2 * (size_t)(m + 1) + 2 * i + 1] + sy; rad[i] = 1.0e4f; lvl[i] = -1; }
+      } else
       for (int i = 0; i < n0; i++) { u[i] = k0[i].x + sx; v[i] = k0[i].y + sy; rad[i] = 1.0e4f; lvl[i] = -1; }
       nm = orc_search_by_projection_win(&F, n0, NULL, d0, u, v, rad, lvl, lvl, NULL, c->nnratio, c->th_high, 1, slot, sobs, out, NULL);
     } else {
@@ -112,7 +131,7 @@ static void match_one(job_t *J, int t) {
   const double t1 = now_ms();
   J->nmatch[t] = nm;
   J->ms_match[t] = t1 - t0;
-  free(kx); free(oct); free(sobs);
+  free(kx); free(oct); free(sobs); free(xy);
 }
 
 static void *worker(void *arg) {

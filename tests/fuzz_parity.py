@@ -91,6 +91,31 @@ def fuzz_reuse(pkg, oracle, synth, rng, log, cache):
     return ok
 
 
+EUROC_K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)                       # Examples/Monocular/EuRoC.yaml:9-12
+EUROC_D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)       # EuRoC.yaml:14-17
+
+
+def random_geometry(pkg, oracle, rng, keys, W=752, H=480):
+    """The frame geometry as the Frame constructor makes it (Frame.cc:837-899, :379-380): with probability 0.3 the image rectangle
+    and distorted = undistorted keypoints (zero distortion), else undistorted keypoints (EuRoC coefficients, or random ones of
+    either sign) with the undistorted-corner bounds or - a third of those - arbitrary bounds with origin in [-80, 0] and an extent
+    of at least the image.  Returns (keys_un, bounds, D)."""
+    kind = rng.random()
+    if kind < 0.3:
+        return keys, (0.0, float(W), 0.0, float(H)), np.zeros(4, np.float32)
+    if kind < 0.6:
+        D = EUROC_D
+    else:
+        D = np.array([rng.uniform(-0.35, 0.25), rng.uniform(-0.1, 0.1), rng.uniform(-1e-3, 1e-3), rng.uniform(-1e-3, 1e-3)], np.float32)
+    keys_un = pkg.undistort_keypoints(keys, EUROC_K, D)
+    bounds = pkg.image_bounds(W, H, EUROC_K, D)
+    if bounds != oracle.image_bounds(W, H, EUROC_K, D):
+        raise AssertionError("image bounds differ from the oracle for D=%s" % D)
+    if rng.random() < 0.33:
+        bounds = tuple(float(np.float32(b)) for b in (rng.uniform(-80, 0), W + rng.uniform(0, 80), rng.uniform(-80, 0), H + rng.uniform(0, 80)))
+    return keys_un, bounds, D
+
+
 def fuzz_match(pkg, oracle, synth, rng, log, cache):
     if "frames" not in cache:
         frames, offs = synth.make_stream(77, 2)
@@ -109,7 +134,14 @@ def fuzz_match(pkg, oracle, synth, rng, log, cache):
     if rng.random() < 0.3:                                        # corrupt some descriptors: ratio test and TH_HIGH edges
         flip = rng.random(dq.shape) < 0.02
         dq ^= flip.astype(np.uint8) * rng.integers(1, 256, dq.shape, dtype=np.uint8)
-    bounds = (0.0, 752.0, 0.0, 480.0)
+    if rng.random() < 0.5:                                        # a few keypoints on the outermost pixels: undistorted, they leave the grid
+        nb = int(rng.integers(1, 9))
+        kc = kc.copy()
+        pick = rng.choice(nc, min(nb, nc), replace=False)
+        kc["x"][pick] = rng.choice(np.array([0.0, 0.5, 751.0, 751.5], np.float32), len(pick))
+        kc["y"][pick] = rng.choice(np.array([0.0, 0.5, 479.0, 479.5], np.float32), len(pick))
+    kc, bounds, D = random_geometry(pkg, oracle, rng, kc)
+    kq = pkg.undistort_keypoints(kq, EUROC_K, D)
     F = pkg.FrameView(kc, dc, bounds)
     OF = oracle.OracleFrame(kc["x"], kc["y"], kc["octave"], kc["angle"], dc, bounds, sf)
     u = (kq["x"] + np.float32(offs[0][0] - offs[1][0]) + rng.normal(0, 2, nq)).astype(np.float32)
@@ -136,7 +168,7 @@ def fuzz_match(pkg, oracle, synth, rng, log, cache):
     cache.setdefault("stats", {}).setdefault("window_matches", []).append(n_ref)
     ok = n_gpu == n_ref and np.array_equal(moq_gpu, moq_ref) and np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
     if not ok:
-        log("MATCH MISMATCH nq=%d nc=%d mode=%d nnratio=%s th=%d second=%s n=%d/%d" % (nq, nc, mode, nnratio, th, second, n_gpu, n_ref))
+        log("MATCH MISMATCH nq=%d nc=%d mode=%d nnratio=%s th=%d second=%s n=%d/%d bounds=%s D=%s" % (nq, nc, mode, nnratio, th, second, n_gpu, n_ref, bounds, D))
     return ok
 
 
@@ -171,7 +203,7 @@ def fuzz_last_frame(pkg, oracle, synth, rng, log, cache):
     u_right = None
     if stereo:
         u_right = np.where(rng.random(len(k1)) < 0.7, k1["x"] - np.float32(47.9) / np.float32(5.0), np.float32(-1)).astype(np.float32)
-    bounds = (0.0, 752.0, 0.0, 480.0)
+    k1, bounds, D = random_geometry(pkg, oracle, rng, k1)         # current frame: undistorted keypoints, undistorted-corner (or arbitrary) bounds
     th = float(rng.choice([7.0, 15.0, 30.0]))
     F = pkg.FrameView(k1, d1, bounds, u_right=u_right)
     OF = oracle.OracleFrame(k1["x"], k1["y"], k1["octave"], k1["angle"], d1, bounds, sf, u_right=u_right)
@@ -183,7 +215,7 @@ def fuzz_last_frame(pkg, oracle, synth, rng, log, cache):
     cache.setdefault("stats", {}).setdefault("last_frame_matches", []).append(n_ref)
     ok = n_gpu == n_ref and np.array_equal(F.slot, OF.slot) and np.array_equal(F.slot_obs, OF.slot_obs)
     if not ok:
-        log("LAST-FRAME MISMATCH cam=%d stereo=%s th=%s n=%d/%d" % (cam, stereo, th, n_gpu, n_ref))
+        log("LAST-FRAME MISMATCH cam=%d stereo=%s th=%s n=%d/%d bounds=%s D=%s" % (cam, stereo, th, n_gpu, n_ref, bounds, D))
     return ok
 
 
