@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
-    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_undistort_keypoints_batch_device", "orbm_set_profiling", "orbm_set_scan_mode", "orbm_get_last_ms", "orbm_get_stage_ms",
+    "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_undistort_keypoints_batch_device", "orbm_set_profiling", "orbm_set_scan_mode", "orbm_set_hamming_engine", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
 
@@ -167,6 +167,8 @@ def load(build_if_needed=True):
     L.orbm_set_profiling.argtypes = [vp, i32]
     L.orbm_set_scan_mode.argtypes = [vp, i32]
     L.orbm_set_scan_mode.restype = i32
+    L.orbm_set_hamming_engine.argtypes = [vp, i32]
+    L.orbm_set_hamming_engine.restype = i32
     L.orbm_get_last_ms.restype = f32
     L.orbm_get_last_ms.argtypes = [vp]
     L.orbm_get_stage_ms.argtypes = [vp, vp, i32]
@@ -793,6 +795,10 @@ class ORBmatcher:
     def set_scan_mode(self, mode):
         """0 = per frame pair on the device (default), 1 = k_match_scan, 2 = k_match_walk; results do not depend on it."""
         self._check(self.L.orbm_set_scan_mode(self.m, int(mode)), "orbm_set_scan_mode")
+
+    def set_hamming_engine(self, engine):
+        """1 = open-window blocks on the matrix pipe (default), 0 = vector ALU; results do not depend on it."""
+        self._check(self.L.orbm_set_hamming_engine(self.m, int(engine)), "orbm_set_hamming_engine")
 
     def last_ms(self):
         return float(self.L.orbm_get_last_ms(self.m))

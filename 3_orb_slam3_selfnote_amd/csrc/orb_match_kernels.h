@@ -128,6 +128,23 @@ __device__ __forceinline__ bool cand_passes(const QueryWin &w, float x, float y,
   return ok;
 }
 
+// "Open" query: the cell window is the whole 64 x 48 grid, no level filter, and the float window reaches more than one grid
+// cell beyond the image bounds on every side, so |x - u| < r and |y - v| < r hold for every keypoint PosInGrid accepts
+// (those lie within half a cell of the bounds): GetFeaturesInArea returns every in-grid keypoint.
+__device__ __forceinline__ bool query_is_open(const MatchProblemSet &M, const QueryWin &w) {
+  const float cellw = 1.0f / M.inv_w, cellh = 1.0f / M.inv_h;
+  return w.live && !w.checkLevels && w.cx0 == 0 && w.cx1 == 63 && w.cy0 == 0 && w.cy1 == 47 &&
+         w.u - w.r < M.min_x - cellw && w.u + w.r > M.min_x + 65.0f * cellw && w.v - w.r < M.min_y - cellh &&
+         w.v + w.r > M.min_y + 49.0f * cellh;
+}
+// Workgroup-wide vote (every thread of the workgroup calls it with its own query's flags): true <=> the block has a live query
+// and all its live queries are open - such blocks of monocular Key32 problems are served by k_match_scan_mfma (orb_match_mfma.h).
+__device__ __forceinline__ bool block_is_open(bool live, bool open) {
+  const int notOpen = __syncthreads_or(live && !open);
+  const int anyLive = __syncthreads_or(live);
+  return anyLive && !notOpen;
+}
+
 // ---- walk or scan: see k_match_walk below
 #define GRID_CELLS (64 * 48)
 #define WALK_MAX_CELLS 256
@@ -167,7 +184,7 @@ enum { SCAN_PLAIN = 0, SCAN_UR = 1, SCAN_FISHEYE = 2, SCAN_FUSE = 3 };
 // Latency mode (few problems in flight): the candidate chunks of one problem are split over gridDim.z workgroups per query
 // block ("slices"), each writing its own sorted top-8 per query at topk + slice * slice_stride; k_topk_merge folds them.
 template <typename KT, int MODE>
-__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int force) {
+__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int force, int mfma /* open blocks belong to k_match_scan_mfma */) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
   __shared__ CandMeta sMeta[MATCH_CH];
@@ -196,6 +213,8 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
     uint4 a = qp[0], b = qp[1];
     qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
   }
+  const bool open = w.live && query_is_open(M, w);
+  if (MODE == SCAN_PLAIN && sizeof(K) == 4 && mfma && block_is_open(w.live, open)) return;
   K top[MATCH_TOPK];
 #pragma unroll
   for (int j = 0; j < MATCH_TOPK; j++) top[j] = KT::NONE;
@@ -231,13 +250,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   // insertion (16 min/max) runs for the whole wavefront only when some lane would have to park a second one.  With 64 lanes
   // nearly every candidate improves SOME lane's list, so inserting on the spot executes the network for almost every candidate;
   // parked, it runs about once per ten such events.  top[7] is an upper bound of the true 8th best meanwhile, so nothing is lost.
-  // "Open" query: the cell window is the whole 64 x 48 grid, no level filter, and the float window reaches more than one grid
-  // cell beyond the image bounds on every side, so |x - u| < r and |y - v| < r hold for every keypoint PosInGrid accepts
-  // (those lie within half a cell of the bounds).  A wavefront whose live lanes are all open skips the per-candidate tests.
-  const float cellw = 1.0f / M.inv_w, cellh = 1.0f / M.inv_h;
-  const bool open = w.live && !w.checkLevels && w.cx0 == 0 && w.cx1 == 63 && w.cy0 == 0 && w.cy1 == 47 &&
-                    w.u - w.r < M.min_x - cellw && w.u + w.r > M.min_x + 65.0f * cellw && w.v - w.r < M.min_y - cellh &&
-                    w.v + w.r > M.min_y + 49.0f * cellh;
+  // A wavefront whose live lanes are all open (query_is_open) skips the per-candidate tests.
   const bool allOpen = MODE == SCAN_PLAIN && __builtin_amdgcn_ballot_w64(w.live && !open) == 0ull;
   const int nchunks = (n + MATCH_CH - 1) / MATCH_CH;
   const int chunk0 = (int)(((long long)nchunks * blockIdx.z) / gridDim.z), chunk1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / gridDim.z);

@@ -1,0 +1,311 @@
+// orb_match_mfma.h -- the open-window candidate scan of the projection searches on the matrix pipe.
+//
+// BASELINE's "1000 x 1000" setting (and every relocalisation-style search whose windows cover the frame) asks for ALL
+// Hamming distances between the queries and the keypoints of a frame (ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483,
+// inside the loops :99-120 / :2148-2156).  k_match_scan does that with 8 xor + 8 v_bcnt per query-candidate pair and wavefront;
+// the popcount issues at a quarter of the VALU rate (profiles/valu_calib.json), so the scan was vector-issue bound while the
+// matrix pipe idled.  A 256-bit Hamming distance is an exact int8 dot product:
+//
+//     with a_k = bit ? -32 : +32 (candidate) and b_k = bit ? +32 : -32 (query):   sum_k a_k b_k = 1024 (2 ham - 256)
+//
+// so  v_mfma_i32_32x32x32_i8  over the 8 K-steps of 32 bits, started from the accumulator  C[row] = 2^18 + rank[row], leaves
+//
+//     D[row = candidate][col = query] = ham << 11 | rank[candidate]
+//
+// i.e. the REDUCTION KEY ITSELF, without a single vector instruction: rank = position of the candidate in the enumeration order
+// of Frame::GetFeaturesInArea (Frame.cc:781-809: grid column, then row, then insertion order), which decides ties between equal
+// distances (strict <, first minimum wins) exactly as the 23 bits cell << 11 | idx of Key32 do - the rank is the same order,
+// compressed to 11 bits so that it fits below a product-scaled distance (k_match_rank computes it once per frame pair).
+// A candidate that is outside the grid or already held gets C = 2^18 + 2^30: its keys are larger than every real key.
+//
+// Layout of a 32 x 32 tile (guide, MFMA C/D map): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) - a lane owns ONE
+// query (its column) and sees 16 of the tile's 32 candidates; the two lanes of a column keep separate sorted top-8 lists of
+// their halves of the frame, merged at the end.  Every wavefront holds two query tiles (64 queries) as B fragments in registers
+// (the 1024 expanded bytes of a K-step pair never leave them), the candidate tiles are expanded once per workgroup into LDS
+// (bit -> byte by a 4-bit multiply spread and one v_perm_b32) and read back as A fragments by conflict-free ds_read_b128
+// (16-byte chunks of a row rotated by the row index).
+//
+// What is left on the VALU is the selection: min of four keys, one vote, parked insertion (as k_match_scan), with the sorted
+// insertion itself as 1 v_min + 7 v_med3 (new[j] = med3(top[j-1], top[j], t): independent, half the instructions of the
+// compare-exchange chain).
+//
+// Served blocks: 256-query blocks whose live queries are ALL "open" (window = whole grid, no level filter; query_is_open) of
+// monocular problems on frames of at most 2048 keypoints; k_match_scan skips exactly those (same vote), the lists are the same
+// Key32 lists either way, so k_match_resolve and every test are unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+typedef int mf_v16i __attribute__((ext_vector_type(16)));
+
+#define MF_NT 256
+#define MF_TILE 32
+#define MF_REC_BASE (1u << 18)
+#define MF_REC_UNUSABLE ((1u << 18) + (1u << 30))
+#define MF_KEY_LIMIT (1u << 20)   // real keys are < 257 << 11
+
+// One workgroup per frame pair: rank of every keypoint in (grid cell, index) order among the keypoints PosInGrid accepts.
+//   rec[i]       = 2^18 + rank                     keypoint i usable (in the grid, not held by a map point with observations)
+//                  2^18 + 2^30                     otherwise
+//   keyrec[rank] = cell << 11 | i                  the Key32 tie-break bits of the keypoint with that rank
+__global__ __launch_bounds__(MF_NT) void k_match_rank(MatchProblemSet M, uint32_t *rec, uint32_t *keyrec) {
+  __shared__ uint32_t sCell[GRID_CELLS + 4];
+  __shared__ uint16_t sSorted[WALK_MAX_N];
+  __shared__ uint32_t sWaveSum[MF_NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int p = blockIdx.x;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  if (n <= 0 || n > WALK_MAX_N) return;
+  const size_t fo = (size_t)p * M.frame_stride;
+  const float *kp = M.kp + fo * 7;
+  for (int c = tid; c < GRID_CELLS + 4; c += MF_NT) sCell[c] = 0u;
+  __syncthreads();
+  constexpr int PER = WALK_MAX_N / MF_NT;
+  uint32_t kbits[PER], krank[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int i = tid + j * MF_NT;
+    kbits[j] = 0u; krank[j] = 0u;
+    if (i < n) {
+      const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
+      const int oct = __float_as_int(kp[(size_t)i * 7 + 5]);
+      const bool claimed = M.slot[fo + i] >= 0 && M.slot_obs[fo + i];
+      kbits[j] = cand_bits(x, y, oct, claimed, M);
+      if ((kbits[j] >> 25) & 1u) krank[j] = atomicAdd(&sCell[cell_of(kbits[j])], 1u);
+    }
+  }
+  __syncthreads();
+  {  // exclusive prefix sums over the 3072 cells (12 consecutive cells per thread), as k_match_walk
+    constexpr int CPT = GRID_CELLS / MF_NT;
+    uint32_t loc[CPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) { loc[j] = sCell[tid * CPT + j]; sum += loc[j]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) sWaveSum[wid] = inc;
+    __syncthreads();
+    uint32_t off = inc - sum;
+    for (int w2 = 0; w2 < wid; w2++) off += sWaveSum[w2];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) { sCell[tid * CPT + j] = off; off += loc[j]; }
+    if (tid == MF_NT - 1) sCell[GRID_CELLS] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int i = tid + j * MF_NT;
+    if (i < n && ((kbits[j] >> 25) & 1u)) sSorted[sCell[cell_of(kbits[j])] + krank[j]] = (uint16_t)i;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int i = tid + j * MF_NT;
+    if (i >= n) continue;
+    uint32_t r = MF_REC_UNUSABLE;
+    if ((kbits[j] >> 25) & 1u) {
+      const uint32_t cell = cell_of(kbits[j]);
+      const int s = (int)sCell[cell], e = (int)sCell[cell + 1];
+      int before = 0;                                   // insertion order inside a cell = index order (Frame.cc:434-465)
+      for (int t = s; t < e; t++) before += (int)sSorted[t] < i ? 1 : 0;
+      const uint32_t rank = (uint32_t)(s + before);
+      keyrec[fo + rank] = (cell << 11) | (uint32_t)i;
+      if ((kbits[j] >> 24) & 1u) r = MF_REC_BASE + rank;
+    }
+    rec[fo + i] = r;
+  }
+}
+
+// median of three as the min / max expression the backend selects v_med3_u32 for.  NOT inline assembly: the compiler pads the
+// wait states between an MFMA and the first vector instruction that reads its result only for instructions it emitted itself.
+__device__ __forceinline__ uint32_t mf_med3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+// 16 descriptor bits -> 16 bytes: LUT byte 0 for a 0 bit, LUT byte 1 for a 1 bit (v_perm_b32 selectors 0 / 1 pick bytes of src1)
+__device__ __forceinline__ mf_v4i mf_expand16(uint32_t hw, uint32_t lut) {
+  mf_v4i o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t nib = (hw >> (4 * i)) & 0xfu;
+    const uint32_t t = (nib * 0x00204081u) & 0x01010101u;          // bit i of the nibble -> byte i (0 / 1)
+    o[i] = (int)__builtin_amdgcn_perm(0u, lut, t);
+  }
+  return o;
+}
+#define MF_LUT_CAND 0x0000E020u    // candidate: 0 -> +32, 1 -> -32
+#define MF_LUT_QUERY 0x000020E0u   // query:     0 -> -32, 1 -> +32
+
+struct MfList {
+  uint32_t top[MATCH_TOPK];
+  uint32_t pend;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) top[j] = 0xffffffffu;
+    pend = 0xffffffffu;
+  }
+  __device__ __forceinline__ void insert(uint32_t t) {   // sorted insertion; a no-op for t = 0xffffffff
+#pragma unroll
+    for (int j = MATCH_TOPK - 1; j >= 1; j--) top[j] = mf_med3(top[j - 1], top[j], t);
+    top[0] = min(top[0], t);
+  }
+  __device__ __forceinline__ void park(uint32_t t) {     // parked insertion, see k_match_scan
+    const bool pass = t < top[MATCH_TOPK - 1];
+    const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
+    if (passMask) {
+      if (passMask & __builtin_amdgcn_ballot_w64(pend != 0xffffffffu)) {
+        insert(pend);
+        pend = 0xffffffffu;
+      }
+      pend = pass ? t : pend;
+    }
+  }
+  // Every key of the tile goes through the sorted insertion, unconditionally: 8 independent instructions per key and no vote,
+  // no branch, no mask.  With 64 lanes x 16 keys behind every vote "does any key of the tile enter some lane's list" the answer
+  // is yes for nearly every tile of a 1000-keypoint frame (a lane's list changes 8 ln(m / 8) + 8 = 41 times over its 500
+  // candidates, 2600 times per wavefront and list), and the parked insertion then pays two ballots, two scalar branches and a
+  // VCC select per key ON TOP of the insertions (measured: 3700 cycles per tile and wavefront in selection against 1000 for
+  // the MFMAs; tools/mfma_stamps.py).
+  __device__ __forceinline__ void take(const mf_v16i &k) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) insert((uint32_t)k[r]);
+  }
+};
+
+__global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, uint32_t *topk, const uint32_t *rec, const uint32_t *keyrec) {
+  // candidate tile in LDS: 32 rows x 16 chunks of 16 bytes, chunk c of row r at position r * 16 + ((c + r) & 15)
+  __shared__ __align__(16) uint8_t sA[2][MF_TILE * 256];
+  __shared__ __align__(16) uint32_t sRec[2][MF_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const unsigned b = blockIdx.x, qblocks = (unsigned)M.scan_qblocks;   // same XCD-aware order as k_match_scan
+  const int qb = (int)((b >> 3) % qblocks), p = (int)((b & 7u) + 8u * (b / (8u * qblocks)));
+  if (p >= M.npairs) return;
+  const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+  if ((int)(qb * MF_NT) >= nq) return;
+  const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
+  const int q = qb * MF_NT + tid;          // = tile (lane >> 5), column (lane & 31) of this wavefront: the query this lane reports
+  bool live = false, open = false;
+  if (q < nq) {
+    const QueryWin w = load_query(M, qo, q);
+    live = w.live;
+    open = query_is_open(M, w);
+  }
+  if (!block_is_open(live, open)) return;   // k_match_scan serves this block
+  // ---- my two queries' B fragments: column `col` of query tile 0 and of tile 1, bits [32 s + 16 h, 32 s + 16 h + 16) per K-step s
+  mf_v4i B0[8], B1[8];
+  {
+    const int q0 = qb * MF_NT + wid * 64 + col, q1 = q0 + 32;
+    const uint4 *g0 = reinterpret_cast<const uint4 *>(M.qdesc + (qo + (size_t)min(q0, nq - 1)) * 32);
+    const uint4 *g1 = reinterpret_cast<const uint4 *>(M.qdesc + (qo + (size_t)min(q1, nq - 1)) * 32);
+    const uint4 a0 = g0[0], b0 = g0[1], a1 = g1[0], b1 = g1[1];
+    const uint32_t d0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w}, d1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      B0[s] = mf_expand16((d0[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
+      B1[s] = mf_expand16((d1[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
+    }
+  }
+  MfList L0, L1;
+  L0.init(); L1.init();
+  const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
+  const uint32_t *recp = rec + fo;
+  const int ntiles = (n + MF_TILE - 1) / MF_TILE;
+  // staging: 512 (row, chunk) items per tile, two per thread; chunk c = 2 s + h' is halfword h' of descriptor word s
+  const int it_r = tid >> 4, it_c = tid & 15;                         // item tid: row it_r (and it_r + 16), chunk it_c
+  auto load_raw = [&](int t, uint32_t raw[2]) {
+    const int base = t * MF_TILE;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int r = it_r + 16 * k;
+      raw[k] = base + r < n ? desc[(size_t)(base + r) * 8 + (it_c >> 1)] : 0u;
+    }
+  };
+  auto stage = [&](int t, int buf, const uint32_t raw[2]) {
+    const int base = t * MF_TILE;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int r = it_r + 16 * k;
+      const mf_v4i x = mf_expand16((raw[k] >> (16 * (it_c & 1))) & 0xffffu, MF_LUT_CAND);
+      *reinterpret_cast<mf_v4i *>(&sA[buf][(r * 16 + ((it_c + r) & 15)) * 16]) = x;
+    }
+    if (tid < MF_TILE) sRec[buf][tid] = base + tid < n ? recp[base + tid] : MF_REC_UNUSABLE;
+  };
+#ifdef MF_STAMPS   // diagnostic builds only (tools/mfma_stamps.py): cycles per phase, thread 0 of every workgroup
+  long long st_stage = 0, st_mfma = 0, st_sel = 0, st_sync = 0, st_t = __builtin_readcyclecounter();
+  const long long st_begin = st_t;
+#define MSTAMP(acc) do { const long long t_ = __builtin_readcyclecounter(); acc += t_ - st_t; st_t = t_; } while (0)
+#else
+#define MSTAMP(acc) do {} while (0)
+#endif
+  uint32_t raw[2];
+  if (ntiles > 0) {
+    load_raw(0, raw);
+    stage(0, 0, raw);
+    if (ntiles > 1) load_raw(1, raw);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage(t + 1, buf ^ 1, raw);
+    if (t + 2 < ntiles) load_raw(t + 2, raw);
+    MSTAMP(st_stage);
+    mf_v16i c;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const mf_v4i v = *reinterpret_cast<const mf_v4i *>(&sRec[buf][8 * g + 4 * h]);
+      c[4 * g] = v[0]; c[4 * g + 1] = v[1]; c[4 * g + 2] = v[2]; c[4 * g + 3] = v[3];
+    }
+    mf_v16i acc0 = c, acc1 = c;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      const mf_v4i a = *reinterpret_cast<const mf_v4i *>(&sA[buf][(col * 16 + ((2 * s + h + col) & 15)) * 16]);
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[s], acc1, 0, 0, 0);
+    }
+#ifdef MF_STAMPS
+    asm volatile("" :: "v"(acc0), "v"(acc1));
+    MSTAMP(st_mfma);
+#endif
+    L0.take(acc0);
+    L1.take(acc1);
+    MSTAMP(st_sel);
+    __syncthreads();
+    MSTAMP(st_sync);
+  }
+#ifdef MF_STAMPS
+  if (tid == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)blockIdx.x; d[0] = st_stage; d[1] = st_mfma; d[2] = st_sel; d[3] = st_sync; d[4] = st_t - st_begin; d[5] = st_begin; }
+#endif
+  L0.insert(L0.pend);
+  L1.insert(L1.pend);
+  // ---- the two lanes of a column hold the lists of the two halves of the frame: lane h reports tile h, so it sends the partner the
+  // list of the OTHER tile and merges what it receives into its own tile's list
+  uint32_t mine[MATCH_TOPK], other[MATCH_TOPK];
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) {
+    mine[j] = h ? L1.top[j] : L0.top[j];
+    const uint32_t send = h ? L0.top[j] : L1.top[j];
+    other[j] = (uint32_t)__shfl_xor((int)send, 32, 64);
+  }
+  // min(a[i], b[7 - i]) are the 8 smallest of the union (a bitonic sequence), three compare-exchange stages sort them
+  uint32_t mg[MATCH_TOPK];
+#pragma unroll
+  for (int j = 0; j < MATCH_TOPK; j++) mg[j] = min(mine[j], other[MATCH_TOPK - 1 - j]);
+  auto cx = [](uint32_t &lo, uint32_t &hi) { const uint32_t l = min(lo, hi), g2 = max(lo, hi); lo = l; hi = g2; };
+  cx(mg[0], mg[4]); cx(mg[1], mg[5]); cx(mg[2], mg[6]); cx(mg[3], mg[7]);
+  cx(mg[0], mg[2]); cx(mg[1], mg[3]); cx(mg[4], mg[6]); cx(mg[5], mg[7]);
+  cx(mg[0], mg[1]); cx(mg[2], mg[3]); cx(mg[4], mg[5]); cx(mg[6], mg[7]);
+  if (q < nq) {
+    uint32_t out[MATCH_TOPK];
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK; j++) {
+      const uint32_t k = mg[j];
+      const bool real = live && k < MF_KEY_LIMIT;
+      const uint32_t kr = keyrec[fo + (real ? (k & 0x7ffu) : 0u)];
+      out[j] = real ? ((k >> 11) << 23) | kr : 0xffffffffu;
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(topk + (qo + q) * MATCH_TOPK);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+  }
+}

@@ -20,6 +20,7 @@
 #include "../../include/orbhip.h"
 #include "orb_kernels.h"
 #include "orb_match_kernels.h"
+#include "orb_match_mfma.h"
 #include "orb_calib.h"
 #include "orb_project_kernels.h"
 
@@ -1015,6 +1016,8 @@ struct orbm_handle {
   DevBuf d_kp, d_desc, d_ur, d_qdesc, d_qf[4], d_qi[2], d_qfl, d_slot, d_sobs, d_moq, d_bd, d_nm, d_a, d_b, d_c, d_topk;
   DevBuf d_partner, d_qside, d_qany;
   DevBuf d_lfq;       // query arrays written by k_lastframe_project (orbm_search_by_projection_last_frame_batch_device)
+  DevBuf d_rank;      // k_match_rank's two tables (accumulator seeds, Key32 tie-break bits) for k_match_scan_mfma
+  int hamming_engine = 1;   // 1: open-window blocks on the matrix pipe (k_match_scan_mfma), 0: every block in k_match_scan (orbm_set_hamming_engine)
   DevBuf d_block;     // inputs + outputs of one host-pointer search, one block (see search_host)
   int scan_mode = 0;  // SCAN_AUTO / SCAN_DENSE / SCAN_WALK of the projection searches (orbm_set_scan_mode); next_scan_mode: one search only
   int next_scan_mode = -1;
@@ -1039,7 +1042,7 @@ struct orbm_handle {
     }                                                                                         \
   } while (0)
 
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS)
 static void *getenv_ptr(const char *name) { const char *e = getenv(name); return e ? (void *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
 
@@ -1053,6 +1056,7 @@ orbm_t *orbm_create(int device) {
   m->device = device;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return nullptr; }
   if (const char *e = getenv("ORBM_SCAN_MODE")) { const int v = atoi(e); if (v >= SCAN_AUTO && v <= SCAN_WALK) m->scan_mode = v; }   // measurements only; see orbm_set_scan_mode
+  if (const char *e = getenv("ORBM_HAMMING_ENGINE")) m->hamming_engine = atoi(e) ? 1 : 0;                                               // measurements only; see orbm_set_hamming_engine
   return m;
 }
 
@@ -1062,7 +1066,7 @@ void orbm_destroy(orbm_t *m) {
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   DevBuf *bufs[] = {&m->d_kp, &m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qf[2], &m->d_qf[3], &m->d_qi[0], &m->d_qi[1],
                     &m->d_qfl, &m->d_slot, &m->d_sobs, &m->d_moq, &m->d_bd, &m->d_nm, &m->d_a, &m->d_b, &m->d_c, &m->d_topk, &m->d_partner, &m->d_qside, &m->d_qany, &m->scratch[0], &m->scratch[1], &m->scratch[2], &m->scratch[3],
-                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block, &m->d_lfq};
+                    &m->scratch[4], &m->scratch[5], &m->scratch[6], &m->scratch[7], &m->d_block, &m->d_lfq, &m->d_rank};
   for (DevBuf *b : bufs) b->release();
   if (m->pin) (void)hipHostFree(m->pin);
   if (m->ev_ok)
@@ -1093,6 +1097,14 @@ void orbm_set_profiling(orbm_t *m, int enable) {
 int orbm_set_scan_mode(orbm_t *m, int mode) {
   if (!m || mode < SCAN_AUTO || mode > SCAN_WALK) return ORBX_E_ARG;
   m->scan_mode = mode;
+  return 0;
+}
+
+// 1 (default) = the all-keypoints scan of open-window query blocks runs on the matrix pipe (k_match_scan_mfma), 0 = on the vector
+// ALU (k_match_scan) like every other block.  Results do not depend on it.
+int orbm_set_hamming_engine(orbm_t *m, int engine) {
+  if (!m || engine < 0 || engine > 1) return ORBX_E_ARG;
+  m->hamming_engine = engine;
   return 0;
 }
 
@@ -1246,7 +1258,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS)
   M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
 #endif
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
@@ -1271,6 +1283,14 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   if (need > m->d_topk.bytes) {
     MCHECK(m, hipStreamSynchronize(s));
     MCHECK(m, m->d_topk.reserve(need));
+  }
+  // matrix-pipe scan of the open-window query blocks (monocular Key32 problems, batch mode): rank tables for it
+  const int force0 = !k32 ? SCAN_DENSE : (m->next_scan_mode >= 0 ? m->next_scan_mode : m->scan_mode);
+  const bool mfma = m->hamming_engine == 1 && k32 && !fuse && !M.qside && !M.partner && !M.u_right && nslices == 1 && force0 != SCAN_WALK;
+  const size_t nrank = (size_t)(npairs - 1) * frame_stride + maxn;
+  if (mfma && 2 * sizeof(uint32_t) * nrank > m->d_rank.bytes) {
+    MCHECK(m, hipStreamSynchronize(s));
+    MCHECK(m, m->d_rank.reserve(2 * sizeof(uint32_t) * nrank));
   }
   const bool prof = m->profiling && m->ev_ok;
   hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
@@ -1305,13 +1325,19 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (fuse) LAUNCH_WALK(SCAN_FUSE); else if (M.qside) LAUNCH_WALK(SCAN_FISHEYE); else if (M.u_right) LAUNCH_WALK(SCAN_UR); else LAUNCH_WALK(SCAN_PLAIN);
   }
 #undef LAUNCH_WALK
+  if (mfma) {
+    uint32_t *rec = (uint32_t *)m->d_rank.p, *keyrec = rec + nrank;
+    hipLaunchKernelGGL(k_match_rank, dim3(npairs), dim3(MF_NT), 0, s, M, rec, keyrec);
+    hipLaunchKernelGGL(k_match_scan_mfma, dim3(sgrid.x), dim3(MF_NT), 0, s, M, (uint32_t *)m->d_topk.p, (const uint32_t *)rec, (const uint32_t *)keyrec);
+  }
+  const int mf = mfma ? 1 : 0;
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
     if (force == SCAN_WALK) {}                                                                                            \
-    else if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);             \
-    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);  \
-    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);     \
-    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force);                 \
+    else if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);             \
+    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);  \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);     \
+    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, mf);                 \
     if (nslices > 1 && force != SCAN_WALK) hipLaunchKernelGGL((k_topk_merge<KT>), dim3(qblocks, npairs), dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, nslices, force); \
     if (prof) MCHECK(m, hipEventRecord(pev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \

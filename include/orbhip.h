@@ -500,6 +500,12 @@ int orbm_undistort_keypoints_batch_device(orbm_t *m, const orbx_keypoint_t *d_ke
 #define ORBM_SCAN_DENSE 1
 #define ORBM_SCAN_WALK 2
 int orbm_set_scan_mode(orbm_t *m, int mode);
+/* Where the all-keypoints scan of OPEN-window query blocks (window = whole grid, no level filter: BASELINE's 1000 x 1000 setting,
+ * relocalisation-style searches) computes its Hamming distances (ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483):
+ * 1 (default) = as exact int8 dot products on the matrix pipe (k_match_scan_mfma: monocular frames of at most 2048 keypoints,
+ * batch launches), 0 = xor + popcount on the vector ALU (k_match_scan) like every other block.  Results do not depend on it;
+ * the tests run both. */
+int orbm_set_hamming_engine(orbm_t *m, int engine);
 
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */
 void orbm_set_profiling(orbm_t *m, int enable);
