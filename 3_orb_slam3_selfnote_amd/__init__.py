@@ -797,7 +797,8 @@ class ORBmatcher:
         self._check(self.L.orbm_set_scan_mode(self.m, int(mode)), "orbm_set_scan_mode")
 
     def set_hamming_engine(self, engine):
-        """1 = open-window blocks on the matrix pipe (default), 0 = vector ALU; results do not depend on it."""
+        """0 = vector ALU, 1 = open-window blocks on the matrix pipe (k_match_scan_mfma), 2 (default) = as 1 + the lists of all-open frame
+        pairs built inside k_match_resolve (fused form); results do not depend on it."""
         self._check(self.L.orbm_set_hamming_engine(self.m, int(engine)), "orbm_set_hamming_engine")
 
     def last_ms(self):

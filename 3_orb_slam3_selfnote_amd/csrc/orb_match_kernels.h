@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "orb_mfma_util.h"
 
 #define MATCH_NT 256
 
@@ -184,7 +185,8 @@ enum { SCAN_PLAIN = 0, SCAN_UR = 1, SCAN_FISHEYE = 2, SCAN_FUSE = 3 };
 // Latency mode (few problems in flight): the candidate chunks of one problem are split over gridDim.z workgroups per query
 // block ("slices"), each writing its own sorted top-8 per query at topk + slice * slice_stride; k_topk_merge folds them.
 template <typename KT, int MODE>
-__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int force, int mfma /* open blocks belong to k_match_scan_mfma */) {
+__global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, typename KT::T *topk, size_t slice_stride, int force, int mfma /* open blocks belong to k_match_scan_mfma */,
+                                                         const uint32_t *pairflag /* or NULL; pairflag[p] != 0: the fused k_match_resolve makes this pair's lists */) {
   typedef typename KT::T K;
   __shared__ uint4 sDesc[MATCH_CH * 2];
   __shared__ CandMeta sMeta[MATCH_CH];
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(MATCH_NT) void k_match_scan(MatchProblemSet M, type
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
   if ((int)(qb * MATCH_NT) >= nq) return;
+  if (pairflag && pairflag[p]) return;
   if (force != SCAN_DENSE && pair_walks(M, p, n, nq, force, &sVote)) return;   // k_match_walk serves this pair
   const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
   const float *kp = M.kp + fo * 7;
@@ -744,8 +747,18 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 #define RESOLVE_FREE 0xffffffffu
 #define REFRESH_K 4
 #define REQ_WORDS 16  // lane, flags, u, v, r, ur, minl, maxl, descriptor[8]
-template <typename KT, bool LDSCAND>
-__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn, int rforce) {
+// FUSED (Key32, LDSCAND; orb_mfma_util.h): a frame pair ALL of whose live queries are open (pairflag[p], voted by k_match_rank) gets
+// no lists from the scan kernels.  It is resolved in the chunked form, and the lists of a chunk of 64 queries are made at the
+// chunk's turn by the whole workgroup on the matrix pipe (serve_mfma): every wavefront takes an eighth of the keypoints, keeps
+// only those NO COMMITTED CLAIM HOLDS (compacted, so the work shrinks as the frame fills up: by the last chunks nine keypoints in
+// ten are taken), runs them as 32-row A tiles against the chunk's queries (two B tiles built from the posted descriptors) with
+// the keypoint's rank as accumulator seed, and keeps a top-4 per query and wavefront; the requesting lane folds the eight sorted
+// shares.  The same pass serves the (now rare) lists exhausted inside a chunk.  The keypoints sit in LDS at position = rank, so
+// a key's low 11 bits are the position and sPerm gives the index.  What this replaces: the all-pairs scan kernel (0.23 ms per 256
+// frame pairs) and the 36 refresh passes per pair that re-scanned the frame on the vector ALU (70 % of k_match_resolve's 0.29 ms).
+template <typename KT, bool LDSCAND, bool FUSED = false>
+__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn, int rforce,
+                                                                   const uint32_t *rec = nullptr, const uint32_t *keyrec = nullptr, const uint32_t *pairflag = nullptr) {
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
   __shared__ K sTk[MATCH_TOPK * 64];
@@ -771,6 +784,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   uint16_t *sPerm = reinterpret_cast<uint16_t *>(sSlot + maxn);
   uint16_t *sPartner = sPerm + ((maxn + 1) & ~1);   // stereo partner of each keypoint, 0xffff = none (only if M.partner)
   uint8_t *sOct = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(sPartner) + (M.partner ? (maxn + 1) / 2 + 1 : 0));
+  uint32_t *sRank = reinterpret_cast<uint32_t *>(sOct + ((maxn + 3) & ~3));   // FUSED only: accumulator seed of the keypoint at sorted position pos
+  bool fusedPair = false;
+  if constexpr (FUSED) fusedPair = pairflag[p] != 0u;
   int *sFill = sCol + 66;
   for (int i = tid; i < 132; i += 64 * RESOLVE_NW) sCol[i] = 0;
   __syncthreads();
@@ -795,7 +811,12 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
     const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
     const int col = ((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) : 64;
-    const int pos = sCol[col] + atomicAdd(&sFill[col], 1);
+    int pos;
+    uint32_t seed = 0u;
+    if (FUSED && fusedPair) {      // exact (cell, index) order: k_match_rank's rank (column-major cells: the columns stay contiguous)
+      seed = rec[fo + i];
+      pos = col < 64 ? (int)(seed & 0x7ffu) : sCol[64] + atomicAdd(&sFill[64], 1);
+    } else pos = sCol[col] + atomicAdd(&sFill[col], 1);
     sPerm[pos] = (uint16_t)i;
     if (LDSCAND) {   // record and descriptor of keypoint i live at its sorted position
       CandMeta c;
@@ -806,6 +827,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       sDesc[2 * pos] = gd[2 * i];
       sDesc[2 * pos + 1] = gd[2 * i + 1];
     }
+    if (FUSED && fusedPair) sRank[pos] = seed;
   }
   __syncthreads();
   auto octave_of = [&](int idx) -> int {
@@ -933,16 +955,24 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   __shared__ int sVoteR;
   constexpr bool WIDE_OK = sizeof(K) == 4;   // Key32 only: frames of at most 2048 keypoints (the wide list array is 16 KiB)
   constexpr int WN = 64 * RESOLVE_NW;
-  __shared__ K sTkW[WIDE_OK ? MATCH_TOPK * WN : 1];
+  __shared__ __align__(16) K sTkW[WIDE_OK ? MATCH_TOPK * WN : 1];
   __shared__ int sRmin[4], sChg[4], sTake, sNm;   // sRmin / sChg: a ring over the rounds (see below)
   bool wide = false;
-  if (WIDE_OK && !M.serial && !M.partner && M.couple == 0 && !M.qside && rforce != SCAN_DENSE) {
+  if (FUSED && fusedPair) wide = false;   // fused pairs take the chunked form below
+  else if (WIDE_OK && !M.serial && !M.partner && M.couple == 0 && !M.qside && rforce != SCAN_DENSE) {
     wide = pair_walks<WN>(M, p, n, nq, rforce, &sVoteR);   // k_match_walk's rule, voted by this kernel's 512 threads
   }
   if (wide) {
     if (tid == 0) { for (int i = 0; i < 4; i++) { sRmin[i] = 0x7fffffff; sChg[i] = 0; } sTake = 0; sNm = 0; }
     __syncthreads();
     int nmatches = 0;
+#ifdef WIDE_STAMPS   // diagnostic builds only (tools/wide_stamps.py): cycles per phase of the wide form, thread 0 of the workgroup
+    long long ws_build = 0, ws_round = 0, ws_refresh = 0, ws_nround = 0, ws_nrefresh = 0, ws_ncut = 0, ws_t = __builtin_readcyclecounter();
+    const long long ws_begin = ws_t;
+#define WSTMP(acc) do { const long long t_ = __builtin_readcyclecounter(); acc += t_ - ws_t; ws_t = t_; } while (0)
+#else
+#define WSTMP(acc) do {} while (0)
+#endif
     for (int base = 0; base < nq; base += WN) {
       const int q = base + tid;
       const int cnt = min(WN, nq - base);
@@ -985,6 +1015,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       // fresh lists for every lane with `want`, RESOLVE_NW requests per pass, all wavefronts serving (serve() as in the chunked form)
       auto refresh = [&](bool want) {
         bool todo = want;
+        WSTMP(ws_round);
         for (;;) {
           __syncthreads();                       // sTake == 0 here (reset at the end of the previous pass / at start)
           int slot = -1;
@@ -1030,13 +1061,21 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
             capm1 = REFRESH_K - 1;
             load_list();
           }
+#ifdef WIDE_STAMPS
+          ws_nrefresh++;
+#endif
         }
+        WSTMP(ws_refresh);
       };
       uint32_t D = 0;
       int my_bd = 256, res_idx = -1, res_bd = 256;
       int s = 0, par = 0;
       bool first_round = true;
+      WSTMP(ws_build);
       while (s < cnt) {
+#ifdef WIDE_STAMPS
+        ws_ncut++;
+#endif
         int r;
         for (;;) {
           const bool pend = tid >= s && tid < cnt;
@@ -1058,6 +1097,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           // a round's words are cleared two rounds later, when every thread is past the barriers behind which it read them
           const int cur = par & 3;
           par++;
+#ifdef WIDE_STAMPS
+          ws_nround++;
+#endif
           if (tid == 0) { sRmin[(cur + 2) & 3] = 0x7fffffff; sChg[(cur + 2) & 3] = 0; }
           if (flagged) atomicMin(&sRmin[cur], tid);
           __syncthreads();
@@ -1095,6 +1137,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         if (M.best_dist) M.best_dist[qo + q] = res_bd;
       }
     }
+    WSTMP(ws_round);
+#ifdef WIDE_STAMPS
+    if (tid == 0 && M.dbg) { long long *d = M.dbg + 16 * (size_t)p; d[0] = ws_build; d[1] = ws_round; d[2] = ws_refresh; d[3] = ws_nround; d[4] = ws_nrefresh; d[5] = ws_ncut; d[6] = ws_t - ws_begin; d[7] = nq; }
+#endif
     if (lane == 0 && nmatches) atomicAdd(&sNm, nmatches);
     __syncthreads();
     if (tid == 0 && M.nmatches) M.nmatches[p] = sNm;
@@ -1104,6 +1150,111 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     }
     return;
   }
+  // ---- FUSED: lists on the matrix pipe (see the comment above the kernel).  Work areas in the wide form's list array, which a fused
+  // pair does not use: [request descriptors 64 x 8 words][shares 64 x 8 wavefronts x 4 keys][compacted positions 8 x 256 u16][seeds 8 x 32]
+  constexpr int CMP_CAP = 256;                                // a wavefront's eighth of at most 2048 keypoints
+  static_assert(!FUSED || (64 * 8 + 64 * RESOLVE_NW * REFRESH_K + RESOLVE_NW * CMP_CAP / 2 + RESOLVE_NW * MF_TILE) * 4 <= MATCH_TOPK * WN * (int)sizeof(K), "work areas exceed the list array");
+  uint32_t *sReqD = reinterpret_cast<uint32_t *>(sTkW);
+  uint32_t *sPartF = sReqD + 64 * 8;
+  uint16_t *sCmpF = reinterpret_cast<uint16_t *>(sPartF + 64 * RESOLVE_NW * REFRESH_K);
+  uint32_t *sSeedF = reinterpret_cast<uint32_t *>(sCmpF + RESOLVE_NW * CMP_CAP);
+  auto serve_mfma = [&](int m) {   // all wavefronts; m <= 64 requests posted in sReqD (their queries are open: every usable keypoint is a candidate)
+    if constexpr (FUSED) {
+      const int col = lane & 31, h = lane >> 5;
+      const int nin = sCol[64];                               // the keypoints PosInGrid accepts are positions [0, nin)
+      const int lo = (int)(((long long)nin * wid) / RESOLVE_NW), hi = (int)(((long long)nin * (wid + 1)) / RESOLVE_NW);
+      uint16_t *cmp = sCmpF + wid * CMP_CAP;
+      int kw = 0;
+      for (int b0 = lo; b0 < hi; b0 += 64) {                  // my eighth, compacted to the keypoints no committed claim holds
+        const int pos = b0 + lane;
+        bool keep = false;
+        if (pos < hi) keep = !(sRank[pos] & MF_REC_HELD) && sOwner[sPerm[pos]] != 0u;
+        const unsigned long long mk = __ballot(keep);
+        if (keep) cmp[kw + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+        kw += __popcll(mk);
+      }
+      const bool two = m > 32;
+      mf_v4i B0[8], B1[8];
+      {
+        const uint4 *r0 = reinterpret_cast<const uint4 *>(sReqD + col * 8), *r1 = reinterpret_cast<const uint4 *>(sReqD + (32 + col) * 8);
+        const uint4 a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+        const uint32_t d0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w}, d1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          B0[s] = mf_expand16((d0[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
+          B1[s] = mf_expand16((d1[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
+        }
+      }
+      MfList<REFRESH_K> L0, L1;
+      L0.init(); L1.init();
+      uint32_t *seedw = sSeedF + wid * MF_TILE;
+      for (int t0 = 0; t0 < kw; t0 += MF_TILE) {
+        const int e = t0 + col;
+        const bool have = e < kw;
+        const int pos = have ? (int)cmp[e] : 0;
+        if (h == 0) seedw[col] = have ? sRank[pos] : MF_REC_UNUSABLE;
+        // A fragments straight from the keypoint's descriptor: bits [32 s + 16 h, 32 s + 16 h + 16) of row `col` per K-step s
+        const uint4 da = sDesc[2 * pos], db = sDesc[2 * pos + 1];
+        const uint32_t dd[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+        mf_v4i A[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) A[s] = mf_expand16((dd[s] >> (16 * h)) & 0xffffu, MF_LUT_CAND);
+        mf_v16i c;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const mf_v4i v4 = *reinterpret_cast<const mf_v4i *>(&seedw[8 * g + 4 * h]);
+          c[4 * g] = v4[0]; c[4 * g + 1] = v4[1]; c[4 * g + 2] = v4[2]; c[4 * g + 3] = v4[3];
+        }
+        mf_v16i acc0 = c;
+#pragma unroll
+        for (int s = 0; s < 8; s++) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B0[s], acc0, 0, 0, 0);
+        L0.take(acc0);
+        if (two) {
+          mf_v16i acc1 = c;
+#pragma unroll
+          for (int s = 0; s < 8; s++) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B1[s], acc1, 0, 0, 0);
+          L1.take(acc1);
+        }
+      }
+      // lane h of a column reports request h * 32 + col: it sends the partner the other tile's list and merges what it receives
+      // (two sorted 4-lists: min(a[i], b[3 - i]) is bitonic, two compare-exchange stages sort it)
+      static_assert(REFRESH_K == 4, "the merge network below is written for 4 keys");
+      uint32_t mg[REFRESH_K];
+#pragma unroll
+      for (int j = 0; j < REFRESH_K; j++) {
+        const uint32_t send = h ? L0.top[REFRESH_K - 1 - j] : L1.top[REFRESH_K - 1 - j];
+        const uint32_t other = (uint32_t)__shfl_xor((int)send, 32, 64);
+        mg[j] = min(h ? L1.top[j] : L0.top[j], other);
+      }
+      auto cxu = [](uint32_t &a, uint32_t &b) { const uint32_t l = min(a, b), g2 = max(a, b); a = l; b = g2; };
+      cxu(mg[0], mg[2]); cxu(mg[1], mg[3]);
+      cxu(mg[0], mg[1]); cxu(mg[2], mg[3]);
+      const int req = h * 32 + col;
+      if (req < m) *reinterpret_cast<uint4 *>(sPartF + ((size_t)req * RESOLVE_NW + wid) * REFRESH_K) = make_uint4(mg[0], mg[1], mg[2], mg[3]);
+    }
+  };
+  // requesting lane: fold the RESOLVE_NW sorted shares of request `rank`, turn the keys (distance << 11 | position) into list entries
+  auto fold_mfma = [&](int rank, K *colp /* column of the chunk's list array, stride 64 */) {
+    if constexpr (FUSED) {
+      auto cxu = [](uint32_t &a, uint32_t &b) { const uint32_t l = min(a, b), g2 = max(a, b); a = l; b = g2; };
+      const uint4 *sh = reinterpret_cast<const uint4 *>(sPartF + (size_t)rank * RESOLVE_NW * REFRESH_K);
+      uint4 v = sh[0];
+      uint32_t a[REFRESH_K] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int w2 = 1; w2 < RESOLVE_NW; w2++) {
+        v = sh[w2];
+        a[0] = min(a[0], v.w); a[1] = min(a[1], v.z); a[2] = min(a[2], v.y); a[3] = min(a[3], v.x);
+        cxu(a[0], a[2]); cxu(a[1], a[3]);
+        cxu(a[0], a[1]); cxu(a[2], a[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < MATCH_TOPK; j++) {
+        K o = KT::NONE;
+        if (j < REFRESH_K && a[j] < MF_KEY_LIMIT) o = (K)(((a[j] >> 11) << 23) | (uint32_t)sPerm[a[j] & 0x7ffu]);
+        colp[64 * j] = o;
+      }
+    }
+  };
 #ifdef RESOLVE_STAMPS
   long long t_round = 0, t_refresh = 0, n_refresh = 0, n_batch = 0, t_chunk = 0, n_round = 0, t_sub[6] = {0, 0, 0, 0, 0, 0}, sub_m = 0;
   long long t0 = __builtin_readcyclecounter();
@@ -1114,7 +1265,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       __syncthreads();                 // (A) requests posted
       const int m = sCmd;
       if (m < 0) break;
-      {
+      if (FUSED && fusedPair) serve_mfma(m);
+      else {
         const int np = shares_of(m), mp = RESOLVE_NW / np, rq = wid & (mp - 1);
         if (rq < m) serve(rq, wid / mp, np);
       }
@@ -1135,7 +1287,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       const bool ob = (myfl >> 1) & 1u;
       uint32_t qpar[6] = {0, 0, 0, 0, 0, 0}, qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + lane] = q < nq ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
+      for (int j = 0; j < MATCH_TOPK; j++) sTk[64 * j + lane] = (q < nq && !(FUSED && fusedPair)) ? topk[(qo + q) * MATCH_TOPK + j] : KT::NONE;
       if (q < nq) {
         qpar[0] = __float_as_uint(M.qu[qo + q]); qpar[1] = __float_as_uint(M.qv[qo + q]); qpar[2] = __float_as_uint(M.qr[qo + q]);
         qpar[3] = __float_as_uint(M.qur ? M.qur[qo + q] : 0.f);
@@ -1176,6 +1328,24 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
 #endif
         const bool mineF = (F >> lane) & 1ull;
         unsigned long long todo = F;
+        if (FUSED && fusedPair && todo) {    // one pass of the whole workgroup on the matrix pipe serves every request
+          const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+          if (mineF) {
+            uint4 *R = reinterpret_cast<uint4 *>(sReqD + rank * 8);
+            R[0] = make_uint4(qd[0], qd[1], qd[2], qd[3]);
+            R[1] = make_uint4(qd[4], qd[5], qd[6], qd[7]);
+          }
+          const int m = (int)__popcll(todo);
+          if (lane == 0) sCmd = m;
+          __syncthreads();             // (A)
+          serve_mfma(m);
+          __syncthreads();             // (B)
+          if (mineF) fold_mfma(rank, sTk + lane);
+          todo = 0ull;
+#ifdef RESOLVE_STAMPS
+          n_batch++;
+#endif
+        }
         while (todo) {
           const int rank = __popcll(todo & ((1ull << lane) - 1ull));
           const bool take = ((todo >> lane) & 1ull) && rank < RESOLVE_NW;
@@ -1238,6 +1408,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         t_refresh += __builtin_readcyclecounter() - ts0; n_refresh += __popcll(F);
 #endif
       };
+      if (FUSED && fusedPair) {              // the chunk's lists, made now: only keypoints without a committed claim enter
+        const unsigned long long want = __ballot(q < nq && (myfl & 1u));
+        if (want) refresh(want);
+      }
       uint32_t D = 0;
       int my_bd = 256, res_idx = -1, res_bd = 256;
 #ifdef RESOLVE_STAMPS

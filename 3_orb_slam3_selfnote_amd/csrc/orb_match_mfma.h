@@ -1,61 +1,35 @@
-// orb_match_mfma.h -- the open-window candidate scan of the projection searches on the matrix pipe.
-//
-// BASELINE's "1000 x 1000" setting (and every relocalisation-style search whose windows cover the frame) asks for ALL
-// Hamming distances between the queries and the keypoints of a frame (ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483,
-// inside the loops :99-120 / :2148-2156).  k_match_scan does that with 8 xor + 8 v_bcnt per query-candidate pair and wavefront;
-// the popcount issues at a quarter of the VALU rate (profiles/valu_calib.json), so the scan was vector-issue bound while the
-// matrix pipe idled.  A 256-bit Hamming distance is an exact int8 dot product:
-//
-//     with a_k = bit ? -32 : +32 (candidate) and b_k = bit ? +32 : -32 (query):   sum_k a_k b_k = 1024 (2 ham - 256)
-//
-// so  v_mfma_i32_32x32x32_i8  over the 8 K-steps of 32 bits, started from the accumulator  C[row] = 2^18 + rank[row], leaves
-//
-//     D[row = candidate][col = query] = ham << 11 | rank[candidate]
-//
-// i.e. the REDUCTION KEY ITSELF, without a single vector instruction: rank = position of the candidate in the enumeration order
-// of Frame::GetFeaturesInArea (Frame.cc:781-809: grid column, then row, then insertion order), which decides ties between equal
-// distances (strict <, first minimum wins) exactly as the 23 bits cell << 11 | idx of Key32 do - the rank is the same order,
-// compressed to 11 bits so that it fits below a product-scaled distance (k_match_rank computes it once per frame pair).
-// A candidate that is outside the grid or already held gets C = 2^18 + 2^30: its keys are larger than every real key.
-//
-// Layout of a 32 x 32 tile (guide, MFMA C/D map): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) - a lane owns ONE
-// query (its column) and sees 16 of the tile's 32 candidates; the two lanes of a column keep separate sorted top-8 lists of
-// their halves of the frame, merged at the end.  Every wavefront holds two query tiles (64 queries) as B fragments in registers
-// (the 1024 expanded bytes of a K-step pair never leave them), the candidate tiles are expanded once per workgroup into LDS
-// (bit -> byte by a 4-bit multiply spread and one v_perm_b32) and read back as A fragments by conflict-free ds_read_b128
-// (16-byte chunks of a row rotated by the row index).
-//
-// What is left on the VALU is the selection: min of four keys, one vote, parked insertion (as k_match_scan), with the sorted
-// insertion itself as 1 v_min + 7 v_med3 (new[j] = med3(top[j-1], top[j], t): independent, half the instructions of the
-// compare-exchange chain).
-//
-// Served blocks: 256-query blocks whose live queries are ALL "open" (window = whole grid, no level filter; query_is_open) of
-// monocular problems on frames of at most 2048 keypoints; k_match_scan skips exactly those (same vote), the lists are the same
-// Key32 lists either way, so k_match_resolve and every test are unchanged.
+// orb_match_mfma.h -- k_match_rank and k_match_scan_mfma: the open-window candidate scan of the projection searches on the matrix
+// pipe (formulation, operand layout and selection: orb_mfma_util.h).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-typedef int mf_v4i __attribute__((ext_vector_type(4)));
-typedef int mf_v16i __attribute__((ext_vector_type(16)));
-
-#define MF_NT 256
-#define MF_TILE 32
-#define MF_REC_BASE (1u << 18)
-#define MF_REC_UNUSABLE ((1u << 18) + (1u << 30))
-#define MF_KEY_LIMIT (1u << 20)   // real keys are < 257 << 11
+#include "orb_mfma_util.h"
 
 // One workgroup per frame pair: rank of every keypoint in (grid cell, index) order among the keypoints PosInGrid accepts.
 //   rec[i]       = 2^18 + rank                     keypoint i usable (in the grid, not held by a map point with observations)
-//                  2^18 + 2^30                     otherwise
+//                  2^18 + rank + 2^30              in the grid, but held: bit 30 lifts its keys above every real key
+//                  2^18 + 2^30                     outside the grid
 //   keyrec[rank] = cell << 11 | i                  the Key32 tie-break bits of the keypoint with that rank
-__global__ __launch_bounds__(MF_NT) void k_match_rank(MatchProblemSet M, uint32_t *rec, uint32_t *keyrec) {
+// and the pair's vote: pairflag[p] = 1 <=> fuse_ok, 1 <= n <= 2048, the pair has a live query and every live query is open - the
+// fused form of k_match_resolve then builds this pair's lists itself and the scan kernels leave it alone.
+__global__ __launch_bounds__(MF_NT) void k_match_rank(MatchProblemSet M, uint32_t *rec, uint32_t *keyrec, uint32_t *pairflag, int fuse_ok) {
   __shared__ uint32_t sCell[GRID_CELLS + 4];
   __shared__ uint16_t sSorted[WALK_MAX_N];
   __shared__ uint32_t sWaveSum[MF_NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
+  {
+    const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
+    const size_t qo = (size_t)p * M.query_stride;
+    bool anyLive = false, notOpen = false;
+    if (fuse_ok && n >= 1 && n <= WALK_MAX_N)
+      for (int q = tid; q < nq; q += MF_NT) {
+        const QueryWin w = load_query(M, qo, q);
+        anyLive = anyLive || w.live;
+        notOpen = notOpen || (w.live && !query_is_open(M, w));
+      }
+    const int bad = __syncthreads_or(notOpen), alive = __syncthreads_or(anyLive);
+    if (tid == 0) pairflag[p] = (alive && !bad) ? 1u : 0u;
+  }
   if (n <= 0 || n > WALK_MAX_N) return;
   const size_t fo = (size_t)p * M.frame_stride;
   const float *kp = M.kp + fo * 7;
@@ -111,67 +85,13 @@ __global__ __launch_bounds__(MF_NT) void k_match_rank(MatchProblemSet M, uint32_
       for (int t = s; t < e; t++) before += (int)sSorted[t] < i ? 1 : 0;
       const uint32_t rank = (uint32_t)(s + before);
       keyrec[fo + rank] = (cell << 11) | (uint32_t)i;
-      if ((kbits[j] >> 24) & 1u) r = MF_REC_BASE + rank;
+      r = MF_REC_BASE + rank + (((kbits[j] >> 24) & 1u) ? 0u : MF_REC_HELD);
     }
     rec[fo + i] = r;
   }
 }
 
-// median of three as the min / max expression the backend selects v_med3_u32 for.  NOT inline assembly: the compiler pads the
-// wait states between an MFMA and the first vector instruction that reads its result only for instructions it emitted itself.
-__device__ __forceinline__ uint32_t mf_med3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
-
-// 16 descriptor bits -> 16 bytes: LUT byte 0 for a 0 bit, LUT byte 1 for a 1 bit (v_perm_b32 selectors 0 / 1 pick bytes of src1)
-__device__ __forceinline__ mf_v4i mf_expand16(uint32_t hw, uint32_t lut) {
-  mf_v4i o;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint32_t nib = (hw >> (4 * i)) & 0xfu;
-    const uint32_t t = (nib * 0x00204081u) & 0x01010101u;          // bit i of the nibble -> byte i (0 / 1)
-    o[i] = (int)__builtin_amdgcn_perm(0u, lut, t);
-  }
-  return o;
-}
-#define MF_LUT_CAND 0x0000E020u    // candidate: 0 -> +32, 1 -> -32
-#define MF_LUT_QUERY 0x000020E0u   // query:     0 -> -32, 1 -> +32
-
-struct MfList {
-  uint32_t top[MATCH_TOPK];
-  uint32_t pend;
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int j = 0; j < MATCH_TOPK; j++) top[j] = 0xffffffffu;
-    pend = 0xffffffffu;
-  }
-  __device__ __forceinline__ void insert(uint32_t t) {   // sorted insertion; a no-op for t = 0xffffffff
-#pragma unroll
-    for (int j = MATCH_TOPK - 1; j >= 1; j--) top[j] = mf_med3(top[j - 1], top[j], t);
-    top[0] = min(top[0], t);
-  }
-  __device__ __forceinline__ void park(uint32_t t) {     // parked insertion, see k_match_scan
-    const bool pass = t < top[MATCH_TOPK - 1];
-    const unsigned long long passMask = __builtin_amdgcn_ballot_w64(pass);
-    if (passMask) {
-      if (passMask & __builtin_amdgcn_ballot_w64(pend != 0xffffffffu)) {
-        insert(pend);
-        pend = 0xffffffffu;
-      }
-      pend = pass ? t : pend;
-    }
-  }
-  // Every key of the tile goes through the sorted insertion, unconditionally: 8 independent instructions per key and no vote,
-  // no branch, no mask.  With 64 lanes x 16 keys behind every vote "does any key of the tile enter some lane's list" the answer
-  // is yes for nearly every tile of a 1000-keypoint frame (a lane's list changes 8 ln(m / 8) + 8 = 41 times over its 500
-  // candidates, 2600 times per wavefront and list), and the parked insertion then pays two ballots, two scalar branches and a
-  // VCC select per key ON TOP of the insertions (measured: 3700 cycles per tile and wavefront in selection against 1000 for
-  // the MFMAs; tools/mfma_stamps.py).
-  __device__ __forceinline__ void take(const mf_v16i &k) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) insert((uint32_t)k[r]);
-  }
-};
-
-__global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, uint32_t *topk, const uint32_t *rec, const uint32_t *keyrec) {
+__global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, uint32_t *topk, const uint32_t *rec, const uint32_t *keyrec, const uint32_t *pairflag) {
   // candidate tile in LDS: 32 rows x 16 chunks of 16 bytes, chunk c of row r at position r * 16 + ((c + r) & 15)
   __shared__ __align__(16) uint8_t sA[2][MF_TILE * 256];
   __shared__ __align__(16) uint32_t sRec[2][MF_TILE];
@@ -183,6 +103,7 @@ __global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, ui
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
   const int nq = M.query_n ? M.query_n[(size_t)p * M.query_n_stride] : M.query_n_const;
   if ((int)(qb * MF_NT) >= nq) return;
+  if (pairflag[p]) return;                 // the fused k_match_resolve builds this pair's lists itself
   const size_t fo = (size_t)p * M.frame_stride, qo = (size_t)p * M.query_stride;
   const int q = qb * MF_NT + tid;          // = tile (lane >> 5), column (lane & 31) of this wavefront: the query this lane reports
   bool live = false, open = false;
@@ -206,7 +127,7 @@ __global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, ui
       B1[s] = mf_expand16((d1[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
     }
   }
-  MfList L0, L1;
+  MfList<MATCH_TOPK> L0, L1;
   L0.init(); L1.init();
   const uint32_t *desc = reinterpret_cast<const uint32_t *>(M.desc + fo * 32);
   const uint32_t *recp = rec + fo;
@@ -276,8 +197,6 @@ __global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, ui
 #ifdef MF_STAMPS
   if (tid == 0 && M.dbg) { long long *d = M.dbg + 8 * (size_t)blockIdx.x; d[0] = st_stage; d[1] = st_mfma; d[2] = st_sel; d[3] = st_sync; d[4] = st_t - st_begin; d[5] = st_begin; }
 #endif
-  L0.insert(L0.pend);
-  L1.insert(L1.pend);
   // ---- the two lanes of a column hold the lists of the two halves of the frame: lane h reports tile h, so it sends the partner the
   // list of the OTHER tile and merges what it receives into its own tile's list
   uint32_t mine[MATCH_TOPK], other[MATCH_TOPK];

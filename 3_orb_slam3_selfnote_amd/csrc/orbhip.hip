@@ -150,7 +150,8 @@ static hipError_t raise_lds_limits(int device) {
                        reinterpret_cast<const void *>(&k_octree<1024, true>), reinterpret_cast<const void *>(&k_octree<1024, false>),
                        reinterpret_cast<const void *>(&k_resize),
                        reinterpret_cast<const void *>(&k_match_resolve<Key32, true>), reinterpret_cast<const void *>(&k_match_resolve<Key32, false>),
-                       reinterpret_cast<const void *>(&k_match_resolve<Key64, true>), reinterpret_cast<const void *>(&k_match_resolve<Key64, false>)};
+                       reinterpret_cast<const void *>(&k_match_resolve<Key64, true>), reinterpret_cast<const void *>(&k_match_resolve<Key64, false>),
+                       reinterpret_cast<const void *>(&k_match_resolve<Key32, true, true>), reinterpret_cast<const void *>(&k_pyramid_chain)};
   for (const void *fn : fns) {
     hipFuncAttributes a;
     hipError_t e = hipFuncGetAttributes(&a, fn);
@@ -1017,7 +1018,7 @@ struct orbm_handle {
   DevBuf d_partner, d_qside, d_qany;
   DevBuf d_lfq;       // query arrays written by k_lastframe_project (orbm_search_by_projection_last_frame_batch_device)
   DevBuf d_rank;      // k_match_rank's two tables (accumulator seeds, Key32 tie-break bits) for k_match_scan_mfma
-  int hamming_engine = 1;   // 1: open-window blocks on the matrix pipe (k_match_scan_mfma), 0: every block in k_match_scan (orbm_set_hamming_engine)
+  int hamming_engine = 2;   // orbm_set_hamming_engine: 0 vector ALU, 1 k_match_scan_mfma, 2 (default) + lists built inside k_match_resolve for all-open pairs
   DevBuf d_block;     // inputs + outputs of one host-pointer search, one block (see search_host)
   int scan_mode = 0;  // SCAN_AUTO / SCAN_DENSE / SCAN_WALK of the projection searches (orbm_set_scan_mode); next_scan_mode: one search only
   int next_scan_mode = -1;
@@ -1042,7 +1043,7 @@ struct orbm_handle {
     }                                                                                         \
   } while (0)
 
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS) || defined(WIDE_STAMPS)
 static void *getenv_ptr(const char *name) { const char *e = getenv(name); return e ? (void *)strtoull(e, nullptr, 0) : nullptr; }
 #endif
 
@@ -1056,7 +1057,7 @@ orbm_t *orbm_create(int device) {
   m->device = device;
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return nullptr; }
   if (const char *e = getenv("ORBM_SCAN_MODE")) { const int v = atoi(e); if (v >= SCAN_AUTO && v <= SCAN_WALK) m->scan_mode = v; }   // measurements only; see orbm_set_scan_mode
-  if (const char *e = getenv("ORBM_HAMMING_ENGINE")) m->hamming_engine = atoi(e) ? 1 : 0;                                               // measurements only; see orbm_set_hamming_engine
+  if (const char *e = getenv("ORBM_HAMMING_ENGINE")) { const int v = atoi(e); if (v >= 0 && v <= 2) m->hamming_engine = v; }                                               // measurements only; see orbm_set_hamming_engine
   return m;
 }
 
@@ -1100,10 +1101,12 @@ int orbm_set_scan_mode(orbm_t *m, int mode) {
   return 0;
 }
 
-// 1 (default) = the all-keypoints scan of open-window query blocks runs on the matrix pipe (k_match_scan_mfma), 0 = on the vector
-// ALU (k_match_scan) like every other block.  Results do not depend on it.
+// Where open-window searches compute their Hamming distances: 0 = vector ALU (k_match_scan) like every other block, 1 = the
+// all-keypoints scan of open-window query blocks on the matrix pipe (k_match_scan_mfma), 2 (default) = as 1, and frame pairs ALL of
+// whose queries are open build their lists inside k_match_resolve (fused form: claimed keypoints masked per 512-query super-chunk).
+// Results do not depend on it.
 int orbm_set_hamming_engine(orbm_t *m, int engine) {
-  if (!m || engine < 0 || engine > 1) return ORBX_E_ARG;
+  if (!m || engine < 0 || engine > 2) return ORBX_E_ARG;
   m->hamming_engine = engine;
   return 0;
 }
@@ -1258,7 +1261,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   M.query_n = d_query_n; M.query_n_stride = query_n_stride; M.query_n_const = q->nq;
   M.nnratio = nnratio; M.th_dist = th_dist; M.use_second = use_second;
   M.slot = d_slot; M.slot_obs = d_slot_obs; M.match_of_query = d_moq; M.best_dist = d_bd; M.nmatches = d_nm;
-#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS)
+#if defined(RESOLVE_STAMPS) || defined(WALK_STAMPS) || defined(SCAN_STAMPS) || defined(MF_STAMPS) || defined(WIDE_STAMPS)
   M.dbg = (long long *)getenv_ptr("ORBHIP_DBG_PTR");
 #endif
   M.nleft = m->ext.nleft; M.partner = m->ext.partner; M.qside = m->ext.qside; M.couple = m->ext.couple;
@@ -1286,11 +1289,11 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   }
   // matrix-pipe scan of the open-window query blocks (monocular Key32 problems, batch mode): rank tables for it
   const int force0 = !k32 ? SCAN_DENSE : (m->next_scan_mode >= 0 ? m->next_scan_mode : m->scan_mode);
-  const bool mfma = m->hamming_engine == 1 && k32 && !fuse && !M.qside && !M.partner && !M.u_right && nslices == 1 && force0 != SCAN_WALK;
+  const bool mfma = m->hamming_engine >= 1 && k32 && !fuse && !M.qside && !M.partner && !M.u_right && nslices == 1 && force0 != SCAN_WALK;
   const size_t nrank = (size_t)(npairs - 1) * frame_stride + maxn;
-  if (mfma && 2 * sizeof(uint32_t) * nrank > m->d_rank.bytes) {
+  if (mfma && sizeof(uint32_t) * (2 * nrank + (size_t)npairs) > m->d_rank.bytes) {
     MCHECK(m, hipStreamSynchronize(s));
-    MCHECK(m, m->d_rank.reserve(2 * sizeof(uint32_t) * nrank));
+    MCHECK(m, m->d_rank.reserve(sizeof(uint32_t) * (2 * nrank + (size_t)npairs)));
   }
   const bool prof = m->profiling && m->ev_ok;
   hipEvent_t *pev = m->ev[m->prof_head % PROF_DEPTH];
@@ -1302,7 +1305,9 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const size_t small = sizeof(uint32_t) * (size_t)((maxn + 1) + maxn + (maxn + 1) / 2 + (M.partner ? (maxn + 1) / 2 + 1 : 0) + 2);
   const size_t big = small + sizeof(uint32_t) * (size_t)((maxn + 3) / 4) + 48 * (size_t)maxn;   // + octave bytes, records, descriptors
   const bool ldscand = big <= 136 * 1024;   // + the kernel's static LDS (Key32: wide list array 16 KiB, chunk lists, requests)
-  const size_t lds = ldscand ? big : small;
+  // fused form: + one accumulator seed per keypoint; serial / coupled problems never take the wide form
+  const bool fused = mfma && m->hamming_engine >= 2 && init_th_low < 0 && !M.serial && M.couple == 0 && big + sizeof(uint32_t) * (size_t)maxn <= 138 * 1024;
+  const size_t lds = fused ? big + sizeof(uint32_t) * (size_t)maxn : ldscand ? big : small;
   if (lds > 152 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
   const dim3 rblock(64 * RESOLVE_NW);
   // Window walk (k_match_walk) or full scan (k_match_scan): decided per pair on the device unless a mode is forced; frames beyond
@@ -1325,27 +1330,32 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
     if (fuse) LAUNCH_WALK(SCAN_FUSE); else if (M.qside) LAUNCH_WALK(SCAN_FISHEYE); else if (M.u_right) LAUNCH_WALK(SCAN_UR); else LAUNCH_WALK(SCAN_PLAIN);
   }
 #undef LAUNCH_WALK
+  uint32_t *rec = mfma ? (uint32_t *)m->d_rank.p : nullptr, *keyrec = mfma ? rec + nrank : nullptr, *pairflag = mfma ? keyrec + nrank : nullptr;
   if (mfma) {
-    uint32_t *rec = (uint32_t *)m->d_rank.p, *keyrec = rec + nrank;
-    hipLaunchKernelGGL(k_match_rank, dim3(npairs), dim3(MF_NT), 0, s, M, rec, keyrec);
-    hipLaunchKernelGGL(k_match_scan_mfma, dim3(sgrid.x), dim3(MF_NT), 0, s, M, (uint32_t *)m->d_topk.p, (const uint32_t *)rec, (const uint32_t *)keyrec);
+    hipLaunchKernelGGL(k_match_rank, dim3(npairs), dim3(MF_NT), 0, s, M, rec, keyrec, pairflag, fused ? 1 : 0);
+    hipLaunchKernelGGL(k_match_scan_mfma, dim3(sgrid.x), dim3(MF_NT), 0, s, M, (uint32_t *)m->d_topk.p, (const uint32_t *)rec, (const uint32_t *)keyrec, (const uint32_t *)pairflag);
   }
   const int mf = mfma ? 1 : 0;
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
     if (force == SCAN_WALK) {}                                                                                            \
-    else if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);             \
-    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);  \
-    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0);     \
-    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, mf);                 \
+    else if (fuse) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FUSE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0, (const uint32_t *)nullptr);             \
+    else if (M.qside) hipLaunchKernelGGL((k_match_scan<KT, SCAN_FISHEYE>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0, (const uint32_t *)nullptr);  \
+    else if (M.u_right) hipLaunchKernelGGL((k_match_scan<KT, SCAN_UR>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, 0, (const uint32_t *)nullptr);     \
+    else hipLaunchKernelGGL((k_match_scan<KT, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, force, mf, (const uint32_t *)pairflag);                 \
     if (nslices > 1 && force != SCAN_WALK) hipLaunchKernelGGL((k_topk_merge<KT>), dim3(qblocks, npairs), dim3(MATCH_NT), 0, s, M, (KT::T *)m->d_topk.p, slice_stride, nslices, force); \
     if (prof) MCHECK(m, hipEventRecord(pev[1], s));                                                                     \
     if (init_th_low >= 0)                                                                                                 \
       hipLaunchKernelGGL((k_init_resolve<KT>), dim3(npairs), dim3(64), 2 * (size_t)maxn + 16, s, M, (const KT::T *)m->d_topk.p, init_th_low); \
     else                                                                                                                  \
-      hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn, force);   \
+      hipLaunchKernelGGL((k_match_resolve<KT, LC>), dim3(npairs), rblock, lds, s, M, (const KT::T *)m->d_topk.p, maxn, force, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);   \
   } while (0)
-  if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
+  if (fused) {   // Key32, candidates in LDS: the scan launches as above (they return at once for fused pairs), then the fused resolve
+    hipLaunchKernelGGL((k_match_scan<Key32, SCAN_PLAIN>), sgrid, dim3(MATCH_NT), 0, s, M, (Key32::T *)m->d_topk.p, slice_stride, force, mf, (const uint32_t *)pairflag);
+    if (prof) MCHECK(m, hipEventRecord(pev[1], s));
+    hipLaunchKernelGGL((k_match_resolve<Key32, true, true>), dim3(npairs), rblock, lds, s, M, (const Key32::T *)m->d_topk.p, maxn, force, (const uint32_t *)rec,
+                       (const uint32_t *)keyrec, (const uint32_t *)pairflag);
+  } else if (k32) { if (ldscand) LAUNCH_MATCH(Key32, true); else LAUNCH_MATCH(Key32, false); }
   else     { if (ldscand) LAUNCH_MATCH(Key64, true); else LAUNCH_MATCH(Key64, false); }
 #undef LAUNCH_MATCH
   if (prof) { MCHECK(m, hipEventRecord(pev[2], s)); m->prof_head++; m->ms_valid = true; }

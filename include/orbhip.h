@@ -500,11 +500,15 @@ int orbm_undistort_keypoints_batch_device(orbm_t *m, const orbx_keypoint_t *d_ke
 #define ORBM_SCAN_DENSE 1
 #define ORBM_SCAN_WALK 2
 int orbm_set_scan_mode(orbm_t *m, int mode);
-/* Where the all-keypoints scan of OPEN-window query blocks (window = whole grid, no level filter: BASELINE's 1000 x 1000 setting,
- * relocalisation-style searches) computes its Hamming distances (ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483):
- * 1 (default) = as exact int8 dot products on the matrix pipe (k_match_scan_mfma: monocular frames of at most 2048 keypoints,
- * batch launches), 0 = xor + popcount on the vector ALU (k_match_scan) like every other block.  Results do not depend on it;
- * the tests run both. */
+/* Where open-window searches (window = whole grid, no level filter: BASELINE's 1000 x 1000 setting, relocalisation-style
+ * searches) compute their Hamming distances (ORBmatcher::DescriptorDistance, ORBmatcher.cc:2463-2483):
+ *   0  xor + popcount on the vector ALU (k_match_scan) like every other query block;
+ *   1  open-window query blocks as exact int8 dot products on the matrix pipe (k_match_scan_mfma: monocular frames of at most
+ *      2048 keypoints, batch launches);
+ *   2  (default) as 1, and frame pairs ALL of whose queries are open build their candidate lists inside k_match_resolve (fused
+ *      form): per 512-query super-chunk, with every keypoint a committed claim holds masked out, so that the lists cannot be
+ *      exhausted by earlier claims (ORBmatcher.cc:89-91, :124-130 resolved without the refresh passes).
+ * Results do not depend on it; the tests run all three. */
 int orbm_set_hamming_engine(orbm_t *m, int engine);
 
 /* Time of the last search kernel launch sequence (HIP events on its stream), ms; <0 if profiling is off. */

@@ -1,8 +1,9 @@
 """GPU parity tests of the matrix-pipe candidate scan (k_match_rank + k_match_scan_mfma, csrc/orb_match_mfma.h).
 
 The open-window blocks of a batch launch compute their Hamming distances (ORBmatcher.cc:2463-2483) as exact int8 dot products
-whose accumulator is the reduction key itself.  Every case runs with the matrix-pipe engine and with the vector-ALU scan
-(orbm_set_hamming_engine 1 / 0) and both must equal the CPU oracle's in-order loop (ORBmatcher.cc:99-130): distances, the
+whose accumulator is the reduction key itself; frame pairs all of whose queries are open build their lists inside k_match_resolve
+(fused form, claimed keypoints masked per 512-query super-chunk).  Every case runs with the fused engine, with the matrix-pipe scan
+kernel alone and with the vector-ALU scan (orbm_set_hamming_engine 2 / 1 / 0) and all three must equal the CPU oracle's in-order loop (ORBmatcher.cc:99-130): distances, the
 grid-walk tie order between equal distances, pre-occupied keypoints, keypoints outside the grid, dead queries, frames whose
 keypoint count is not a multiple of the 32-candidate tile, blocks that mix open and windowed queries (served by k_match_scan)."""
 import ctypes as C
@@ -63,7 +64,7 @@ def oracle_pair(oracle, c, q, bounds, sf, nnratio, th, second):
 
 def check(pkg, oracle, cand, qry, bounds, sf, nnratio=0.8, th=100, second=True, min_total=1):
     ref = [oracle_pair(oracle, c, q, bounds, sf, nnratio, th, second) for c, q in zip(cand, qry)]
-    for engine in (1, 0):
+    for engine in (2, 1, 0):
         m = pkg.ORBmatcher(nnratio, True)
         try:
             m.set_hamming_engine(engine)

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--engines", default="1,0")
+ap.add_argument("--engines", default="2,1,0")
 ap.add_argument("--batch", type=int, default=256)
 args = ap.parse_args()
 pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
@@ -50,9 +50,9 @@ for eng in [int(e) for e in args.engines.split(",")]:
     res[eng] = (moq.cpu().numpy().copy(), nm.cpu().numpy().copy())
     print("engine %d: scan %.4f ms  resolve %.4f ms  (mean matches %.1f)" % (eng, st["match_scan"], st["match_resolve"], res[eng][1].mean()), flush=True)
     mt.close()
-if len(res) == 2:
-    a, b = res.values()
+if len(res) >= 2:
+    vals = list(res.values())
     cnt = d_cnt.cpu().numpy()
-    same = all(np.array_equal(a[0][p, :cnt[p, 0]], b[0][p, :cnt[p, 0]]) for p in range(B)) and np.array_equal(a[1], b[1])
+    same = all(all(np.array_equal(vals[0][0][p, :cnt[p, 0]], b[0][p, :cnt[p, 0]]) for p in range(B)) and np.array_equal(vals[0][1], b[1]) for b in vals[1:])
     print("engines agree:", same)
     sys.exit(0 if same else 1)
