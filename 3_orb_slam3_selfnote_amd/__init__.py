@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
-    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
+    "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_triangulation_candidates", "orbm_search_for_triangulation_pred", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
     "orbm_radius_by_viewing_cos", "orbm_project", "orbm_undistort_keypoints", "orbm_image_bounds", "orbm_undistort_keypoints_batch_device", "orbm_set_profiling", "orbm_set_scan_mode", "orbm_set_hamming_engine", "orbm_get_last_ms", "orbm_get_stage_ms",
 ]
 
@@ -61,6 +61,8 @@ class QueryStruct(C.Structure):  # orbm_queries_t
                 ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p), ("u_r", C.c_void_p),
                 ("flags", C.c_void_p)]
 
+
+PAIR_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)   # orbm_pair_predicate_t
 
 _lib = None
 
@@ -151,6 +153,8 @@ def load(build_if_needed=True):
     L.orbm_search_by_bow_keyframes.argtypes = [vp, vp, vp, f32, i32, vp]
     L.orbm_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
     L.orbm_search_for_triangulation.argtypes = [vp] * 10 + [i32, i32, i32, vp]
+    L.orbm_triangulation_candidates.argtypes = [vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, i32]
+    L.orbm_search_for_triangulation_pred.argtypes = [vp, vp, vp, f32, f32, i32, i32, i32, i32, PAIR_PRED, vp, vp]
     L.orbm_search_by_projection_sim3.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp]
     L.orbm_search_by_projection_keyframe.argtypes = [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, i32, i32, vp, vp]
     L.orbm_search_by_projection_last_frame.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32,
@@ -768,6 +772,38 @@ class ORBmatcher:
         self._check(rc, "orbm_search_for_triangulation")
         if rc < 0:
             raise OrbError("orbm_search_for_triangulation rc=%d" % rc)
+        m12 = m12[:KF1.N]
+        i1 = np.nonzero(m12 >= 0)[0]
+        return rc, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
+
+    def TriangulationCandidates(self, KF1, KF2, ep, epipole_gate, bOnlyStereo=False):
+        """orbm_triangulation_candidates: (start[KF1.N + 1], idx2[], dist[]) - per keypoint of KF1 the same-node keypoints of KF2 that
+        pass every gate in front of the epipolar predicate (ORBmatcher.cc:1080-1113), ordered (dist ascending, node position descending)."""
+        s1, s2 = KF1.struct(), KF2.struct()
+        start = np.zeros(KF1.N + 1, np.int32)
+        cap = 4096
+        while True:
+            idx2, dist = np.zeros(max(cap, 1), np.int32), np.zeros(max(cap, 1), np.int32)
+            tot = self.L.orbm_triangulation_candidates(self.m, C.byref(s1), C.byref(s2), C.c_float(ep[0]), C.c_float(ep[1]), int(bool(epipole_gate)),
+                                                       int(bool(bOnlyStereo)), _p(start), _p(idx2), _p(dist), cap)
+            self._check(tot, "orbm_triangulation_candidates")
+            if tot < 0:
+                raise OrbError("orbm_triangulation_candidates rc=%d" % tot)
+            if tot <= cap:
+                return start, idx2[:tot].copy(), dist[:tot].copy()
+            cap = tot
+
+    def SearchForTriangulationPred(self, KF1, KF2, ep, epipole_gate, pred, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation for camera models whose epipolarConstrain is not Pinhole's (KannalaBrandt8, rigs): pred(idx1, idx2) is
+        the caller's predicate (ORBmatcher.cc:1148).  Returns (nmatches, vMatchedPairs [k, 2])."""
+        s1, s2 = KF1.struct(), KF2.struct()
+        m12 = np.full(max(KF1.N, 1), -1, dtype=np.int32)
+        cb = PAIR_PRED(lambda user, i1, i2: 1 if pred(i1, i2) else 0)
+        rc = self.L.orbm_search_for_triangulation_pred(self.m, C.byref(s1), C.byref(s2), C.c_float(ep[0]), C.c_float(ep[1]), int(bool(epipole_gate)),
+                                                       int(bool(bOnlyStereo)), int(bool(bCoarse)), int(self.mbCheckOrientation), cb, None, _p(m12))
+        self._check(rc, "orbm_search_for_triangulation_pred")
+        if rc < 0:
+            raise OrbError("orbm_search_for_triangulation_pred rc=%d" % rc)
         m12 = m12[:KF1.N]
         i1 = np.nonzero(m12 >= 0)[0]
         return rc, np.stack([i1, m12[i1]], axis=1).astype(np.int64)

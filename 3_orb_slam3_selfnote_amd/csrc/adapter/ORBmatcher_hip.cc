@@ -23,14 +23,15 @@
 //   Fuse(KeyFrame*, vpMapPoints, th, bRight) / Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)   :1425-1658 / :1660-1786
 //   DescriptorDistance, ComputeThreeMaxima, RadiusByViewingCos                                      :2463-2483, :2416-2458, :216-222
 //   CheckDistEpipolarLine, CheckDistEpipolarLine2                                                   :225-267   (no call site)
-// The one configuration without a device path: SearchForTriangulation between keyframes whose camera is not a Pinhole model or
-// that carry a second camera (KannalaBrandt8::epipolarConstrain triangulates with cv::SVD) - it
-// throws std::runtime_error instead of silently computing on the CPU.
+// SearchForTriangulation between keyframes whose camera is not a Pinhole model or that carry a second camera: the epipolar test is the
+// reference's own virtual pCamera1->epipolarConstrain (KannalaBrandt8's triangulates with cv::SVD), called
+// as a predicate on the candidate pairs the device delivers (SearchForTriangulationGeneric below); everything else is on the device.
 #include "ORBmatcher.h"  // the reference's header, unmodified
 
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -68,9 +69,14 @@ int checked(int rc) {
 struct MapPointRaw : MapPoint {
   static float MapPoint::*max_distance() { return &MapPointRaw::mfMaxDistance; }
   static float MapPoint::*min_distance() { return &MapPointRaw::mfMinDistance; }
+  static std::mutex MapPoint::*mutex_pos() { return &MapPointRaw::mMutexPos; }
 };
-inline float raw_max_distance(MapPoint *p) { (void)p->GetMaxDistanceInvariance(); return p->*MapPointRaw::max_distance(); }  // the getter takes mMutexPos once
-inline float raw_min_distance(MapPoint *p) { return p->*MapPointRaw::min_distance(); }
+// both distances under mMutexPos, as the getters read them (MapPoint.cc:552-563): LocalMapping's UpdateNormalAndDepth writes them
+inline void raw_distances(MapPoint *p, float &dmax, float &dmin) {
+  std::unique_lock<std::mutex> lock(p->*MapPointRaw::mutex_pos());
+  dmax = p->*MapPointRaw::max_distance();
+  dmin = p->*MapPointRaw::min_distance();
+}
 
 // Frame -> orbm_frame_t.  mvKeysUn is a std::vector<cv::KeyPoint>: its data() already has the 28-byte layout.
 orbm_frame_t view_of(const Frame &F) {
@@ -139,8 +145,7 @@ struct Points {
     vec3(pMP->GetWorldPos(), &Xw[3 * i]);
     vec3(pMP->GetNormal(), &normal[3 * i]);
     std::memcpy(&desc[32 * i], pMP->GetDescriptor().ptr<uint8_t>(), 32);
-    dmax[i] = raw_max_distance(pMP);
-    dmin[i] = raw_min_distance(pMP);
+    raw_distances(pMP, dmax[i], dmin[i]);
   }
 };
 
@@ -351,8 +356,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     vec3(pMP->GetWorldPos(), &Xw[(size_t)i * 3]);
     std::memcpy(&desc[(size_t)i * 32], pMP->GetDescriptor().ptr<uint8_t>(), 32);
     ang[i] = pKF->mvKeysUn[i].angle;                                      // :2378
-    dmax[i] = raw_max_distance(pMP);                                      // the library applies the 1.2f / 0.8f of the getters (:2327-2328)
-    dmin[i] = raw_min_distance(pMP);
+    raw_distances(pMP, dmax[i], dmin[i]);                                 // the library applies the 1.2f / 0.8f of the getters (:2327-2328)
   }
   float Tcw[16];
   mat44(CurrentFrame.mTcw, Tcw);
@@ -480,12 +484,98 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
   return n;
 }
 
+// SearchForTriangulation for KannalaBrandt8 keyframes and two-camera rigs (ORBmatcher.cc:981-1222 with a non-Pinhole
+// epipolarConstrain at :1148).  KannalaBrandt8::epipolarConstrain triangulates with cv::SVD and stays the reference's own code
+// (SURVEY.md section 2 row 4); everything in front of it - the vocabulary-node walk, the Hamming distances, TH_LOW, the stereo
+// filter, the epipole gate - runs on the device (orbm_search_for_triangulation_pred), which then asks this predicate about the
+// surviving pairs in the reference's order of preference.
+namespace {
+struct TriangulationPredicate {
+  KeyFrame *pKF1, *pKF2;
+  bool rig;
+  cv::Mat R12, t12, Rll, Rlr, Rrl, Rrr, tll, tlr, trl, trr;
+  static int call(void *user, int idx1, int idx2) {
+    TriangulationPredicate *c = static_cast<TriangulationPredicate *>(user);
+    KeyFrame *pKF1 = c->pKF1, *pKF2 = c->pKF2;
+    const cv::KeyPoint &kp1 = (pKF1->NLeft == -1) ? pKF1->mvKeysUn[idx1] : (idx1 < pKF1->NLeft) ? pKF1->mvKeys[idx1] : pKF1->mvKeysRight[idx1 - pKF1->NLeft];  // :1064-1066
+    const cv::KeyPoint &kp2 = (pKF2->NLeft == -1) ? pKF2->mvKeysUn[idx2] : (idx2 < pKF2->NLeft) ? pKF2->mvKeys[idx2] : pKF2->mvKeysRight[idx2 - pKF2->NLeft];  // :1099-1101
+    const bool bRight1 = !(pKF1->NLeft == -1 || idx1 < pKF1->NLeft), bRight2 = !(pKF2->NLeft == -1 || idx2 < pKF2->NLeft);
+    GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
+    const cv::Mat *R = &c->R12, *t = &c->t12;
+    if (pKF1->mpCamera2 && pKF2->mpCamera2) {                                        // :1115-1145
+      if (bRight1 && bRight2) { R = &c->Rrr; t = &c->trr; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera2; }
+      else if (bRight1 && !bRight2) { R = &c->Rrl; t = &c->trl; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera; }
+      else if (!bRight1 && bRight2) { R = &c->Rlr; t = &c->tlr; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera2; }
+      else { R = &c->Rll; t = &c->tll; }
+    }
+    return pCamera1->epipolarConstrain(pCamera2, kp1, kp2, *R, *t, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave]) ? 1 : 0;  // :1148
+  }
+};
+
+int SearchForTriangulationGeneric(ORBmatcher *self, KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                                  const bool bOnlyStereo, const bool bCoarse, const bool checkOri) {
+  (void)self;
+  // epipole in the second image and the relative poses, exactly as the reference forms them (:988-1023)
+  cv::Mat Cw = pKF1->GetCameraCenter();
+  cv::Mat R2w = pKF2->GetRotation();
+  cv::Mat t2w = pKF2->GetTranslation();
+  cv::Mat C2 = R2w * Cw + t2w;
+  const cv::Point2f ep = pKF2->mpCamera->project(C2);
+  cv::Mat R1w = pKF1->GetRotation();
+  cv::Mat t1w = pKF1->GetTranslation();
+  TriangulationPredicate P;
+  P.pKF1 = pKF1; P.pKF2 = pKF2;
+  P.rig = pKF1->mpCamera2 != NULL || pKF2->mpCamera2 != NULL;
+  if (!pKF1->mpCamera2 && !pKF2->mpCamera2) {
+    P.R12 = R1w * R2w.t();
+    P.t12 = -R1w * R2w.t() * t2w + t1w;
+  } else {
+    P.Rll = pKF1->GetRotation() * pKF2->GetRotation().t();
+    P.Rlr = pKF1->GetRotation() * pKF2->GetRightRotation().t();
+    P.Rrl = pKF1->GetRightRotation() * pKF2->GetRotation().t();
+    P.Rrr = pKF1->GetRightRotation() * pKF2->GetRightRotation().t();
+    P.tll = pKF1->GetRotation() * (-pKF2->GetRotation().t() * pKF2->GetTranslation()) + pKF1->GetTranslation();
+    P.tlr = pKF1->GetRotation() * (-pKF2->GetRightRotation().t() * pKF2->GetRightTranslation()) + pKF1->GetTranslation();
+    P.trl = pKF1->GetRightRotation() * (-pKF2->GetRotation().t() * pKF2->GetTranslation()) + pKF1->GetRightTranslation();
+    P.trr = pKF1->GetRightRotation() * (-pKF2->GetRightRotation().t() * pKF2->GetRightTranslation()) + pKF1->GetRightTranslation();
+  }
+  struct Side {
+    Nodes nodes; std::vector<uint8_t> has; std::vector<cv::KeyPoint> keys; std::vector<float> ur; orbm_keyframe_t k;
+    explicit Side(KeyFrame *pKF) : nodes(pKF->mFeatVec), has(pKF->N) {
+      std::memset(&k, 0, sizeof(k));
+      for (int i = 0; i < pKF->N; i++) has[i] = pKF->GetMapPoint(i) != NULL;
+      if (pKF->NLeft != -1) { keys = pKF->mvKeys; keys.insert(keys.end(), pKF->mvKeysRight.begin(), pKF->mvKeysRight.end()); }  // :1064-1066
+      else keys = pKF->mvKeysUn;
+      keys.resize(pKF->N);
+      // bStereo = !mpCamera2 && mvuRight[idx] >= 0 (:1059, :1086): always false on a rig
+      if (pKF->mpCamera2 || (int)pKF->mvuRight.size() < pKF->N) ur.assign(pKF->N, -1.0f); else ur = pKF->mvuRight;
+      nodes.into(k);
+      k.n = pKF->N;
+      k.keys_un = reinterpret_cast<const orbx_keypoint_t *>(keys.data());
+      k.descriptors = pKF->mDescriptors.data;
+      k.u_right = ur.data();
+      k.has_mappoint = has.data();
+      k.scale_factors = pKF->mvScaleFactors.data(); k.level_sigma2 = pKF->mvLevelSigma2.data();
+      k.nlevels = (int32_t)pKF->mvScaleFactors.size();
+    }
+  };
+  Side A(pKF1), B(pKF2);
+  std::vector<int32_t> m12(pKF1->N > 0 ? pKF1->N : 1, -1);
+  const int n = checked(orbm_search_for_triangulation_pred(matcher(), &A.k, &B.k, ep.x, ep.y, pKF1->mpCamera2 ? 0 : 1, bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0,
+                                                           checkOri ? 1 : 0, &TriangulationPredicate::call, &P, m12.data()));
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(n);
+  for (int i = 0; i < pKF1->N; i++)
+    if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));  // :1211-1219
+  return n;
+}
+}  // namespace
+
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
                                        const bool bOnlyStereo, const bool bCoarse) {
   (void)F12;  // unused by the reference as well (it appears only in the signature, :981)
   if (pKF1->mpCamera2 || pKF2->mpCamera2 || pKF1->mpCamera->GetType() != 0 || pKF2->mpCamera->GetType() != 0)
-    throw std::runtime_error("ORBmatcher::SearchForTriangulation: only Pinhole keyframes without a second camera have a device path "
-                             "(KannalaBrandt8::epipolarConstrain rests on cv::SVD, outside the path: SURVEY.md section 2 row 4)");
+    return SearchForTriangulationGeneric(this, pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse, mbCheckOrientation);
   struct Side {
     Nodes nodes; std::vector<uint8_t> has; orbm_keyframe_t k;
     explicit Side(KeyFrame *pKF) : nodes(pKF->mFeatVec), has(pKF->N) {

@@ -1687,6 +1687,73 @@ __global__ __launch_bounds__(256) void k_triangulation_match(TriParams T) {
   if (lane == 0) T.matches12[idx1] = best != 0xffffffffu ? T.node_idx2[item.start2 + (0xffff - (int)(best & 0xffff))] : -1;
 }
 
+// SearchForTriangulation for keyframes whose epipolar test is NOT Pinhole's (KannalaBrandt8, two-camera rigs; ORBmatcher.cc:1096-1153
+// with pCamera1->epipolarConstrain(...) a virtual call into code outside this path): the device delivers, per unmatched keypoint of KF1,
+// EVERY keypoint of KF2 in the same vocabulary node that passes the gates in front of the predicate - no map point (:1083), stereo
+// filter (:1088-1090), distance <= TH_LOW (:1096), epipole distance (:1105-1113) - as keys dist << 16 | (0xffff - position); the host
+// orders them and the caller's predicate picks (orbm_search_for_triangulation_pred).  One wavefront per item; the segment of the
+// output buffer comes from one atomicAdd per wavefront, a segment that would not fit is counted but not written.
+struct TriCandParams {
+  const float *kp2;
+  const uint32_t *desc1, *desc2;
+  const float *ur1, *ur2;
+  const uint8_t *hasmp2;
+  const int32_t *node_idx2;
+  const TriItem *items; int nitems;
+  float sf2[ORBX_MAX_LEVELS];
+  float epx, epy;
+  int epipole_gate, bOnlyStereo;
+  int32_t *item_off, *item_cnt;   // per item
+  uint32_t *keys; int cap;        // output buffer
+  int32_t *total;                 // running total (allocation counter)
+};
+
+__global__ __launch_bounds__(256) void k_triangulation_candidates(TriCandParams T) {
+  const int lane = threadIdx.x & 63;
+  const int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (it >= T.nitems) return;
+  const TriItem item = T.items[it];
+  const int idx1 = item.idx1;
+  uint32_t d1[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) d1[w] = T.desc1[(size_t)idx1 * 8 + w];
+  const bool bStereo1 = T.ur1[idx1] >= 0.f;
+  auto key_of = [&](int j) -> uint32_t {      // 0xffffffff: not a candidate
+    const int idx2 = T.node_idx2[item.start2 + j];
+    if (T.hasmp2[idx2]) return 0xffffffffu;                               // :1083 (vbMatched2 is never set)
+    const bool bStereo2 = T.ur2[idx2] >= 0.f;
+    if (T.bOnlyStereo && !bStereo2) return 0xffffffffu;                   // :1088-1090
+    int dist = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) dist += __popc(d1[w] ^ T.desc2[(size_t)idx2 * 8 + w]);
+    if (dist > ORBM_TH_LOW) return 0xffffffffu;                           // :1096
+    if (T.epipole_gate && !bStereo1 && !bStereo2) {                       // :1105-1113
+      const float x2 = T.kp2[(size_t)idx2 * 7], y2 = T.kp2[(size_t)idx2 * 7 + 1];
+      const int oct2 = __float_as_int(T.kp2[(size_t)idx2 * 7 + 5]);
+      const float distex = T.epx - x2, distey = T.epy - y2;
+      if (distex * distex + distey * distey < 100 * T.sf2[oct2 & (ORBX_MAX_LEVELS - 1)]) return 0xffffffffu;
+    }
+    return ((uint32_t)dist << 16) | (uint32_t)(0xffff - j);
+  };
+  int cnt = 0;
+  for (int j0 = 0; j0 < item.len2; j0 += 64) {
+    const int j = j0 + lane;
+    cnt += __popcll(__ballot(j < item.len2 && key_of(j) != 0xffffffffu));
+  }
+  int base = 0;
+  if (lane == 0) { base = cnt ? atomicAdd(T.total, cnt) : 0; T.item_off[it] = base; T.item_cnt[it] = cnt; }
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (cnt == 0 || base + cnt > T.cap) return;
+  int w0 = 0;
+  for (int j0 = 0; j0 < item.len2; j0 += 64) {
+    const int j = j0 + lane;
+    const uint32_t k = j < item.len2 ? key_of(j) : 0xffffffffu;
+    const unsigned long long mk = __ballot(k != 0xffffffffu);
+    if (k != 0xffffffffu) T.keys[base + w0 + __popcll(mk & ((1ull << lane) - 1ull))] = k;
+    w0 += __popcll(mk);
+  }
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) inner loops (ORBmatcher.cc:303-438, Nleft == -1): the
 // keypoints of the frame that fall into a vocabulary node can only be taken by keyframe keypoints of the same node, so
 // the shared nodes are independent problems: one wavefront per shared node.  It walks the node's keyframe keypoints

@@ -2061,6 +2061,138 @@ void inv33(const float *S, float *D) {
 }
 }  // namespace
 
+// merge-walk of the two feature vectors (ORBmatcher.cc:1036-1188): one work item per unmatched keypoint of KF1 in a shared node
+static int triangulation_items(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, int bOnlyStereo, std::vector<TriItem> &items) {
+  int f1 = 0, f2 = 0;
+  while (f1 < k1->n_nodes && f2 < k2->n_nodes) {
+    if (k1->node_id[f1] == k2->node_id[f2]) {
+      const int s2 = k2->node_start[f2], l2 = k2->node_start[f2 + 1] - s2;
+      if (l2 > 0xffff) { m->err = "vocabulary node with more than 65535 keypoints"; return ORBX_E_ARG; }
+      for (int i1 = k1->node_start[f1]; i1 < k1->node_start[f1 + 1]; i1++) {
+        const int idx1 = k1->node_idx[i1];
+        if (idx1 < 0 || idx1 >= k1->n) return ORBX_E_ARG;
+        if (k1->has_mappoint[idx1]) continue;                          // :1050-1055
+        if (bOnlyStereo && !(k1->u_right[idx1] >= 0)) continue;        // :1057-1061
+        if (l2 > 0) items.push_back(TriItem{idx1, s2, l2});
+      }
+      f1++; f2++;
+    } else if (k1->node_id[f1] < k2->node_id[f2]) {
+      while (f1 < k1->n_nodes && k1->node_id[f1] < k2->node_id[f2]) f1++;
+    } else {
+      while (f2 < k2->n_nodes && k2->node_id[f2] < k1->node_id[f1]) f2++;
+    }
+  }
+  return 0;
+}
+
+// Candidate lists of SearchForTriangulation, per keypoint of KF1 in CSR form: start[k1->n + 1]; per candidate the keypoint of KF2 and
+// the distance, ordered (distance ascending, position in the node descending) = the order in which the reference's running best
+// would prefer them ("dist > bestDist -> skip", update on <=: the LAST minimum among the candidates its predicate accepts).
+static int triangulation_candidates(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, float ep_x, float ep_y, int epipole_gate,
+                                    int bOnlyStereo, std::vector<int32_t> &start, std::vector<int32_t> &idx2, std::vector<int32_t> &dist) {
+  start.assign((size_t)k1->n + 1, 0);
+  idx2.clear(); dist.clear();
+  if (k1->n == 0 || k2->n == 0 || k1->n_nodes == 0 || k2->n_nodes == 0) return 0;
+  std::vector<TriItem> items;
+  const int rc = triangulation_items(m, k1, k2, bOnlyStereo, items);
+  if (rc < 0) return rc;
+  if (items.empty()) return 0;
+  MCHECK(m, hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const size_t nidx2 = (size_t)k2->node_start[k2->n_nodes];
+  DevBuf *B[] = {&m->d_desc, &m->d_ur, &m->d_qdesc, &m->d_qf[0], &m->d_qf[1], &m->d_qfl, &m->d_qi[0], &m->d_qi[1]};
+  const void *src[] = {k1->descriptors, k1->u_right, k2->descriptors, k2->keys_un, k2->u_right, k2->has_mappoint, k2->node_idx, items.data()};
+  const size_t bytes[] = {32 * (size_t)k1->n, sizeof(float) * (size_t)k1->n, 32 * (size_t)k2->n, sizeof(orbx_keypoint_t) * (size_t)k2->n,
+                          sizeof(float) * (size_t)k2->n, (size_t)k2->n, sizeof(int32_t) * nidx2, sizeof(TriItem) * items.size()};
+  for (int i = 0; i < 8; i++) {
+    MCHECK(m, B[i]->reserve(std::max<size_t>(bytes[i], 4)));
+    MCHECK(m, hipMemcpyAsync(B[i]->p, src[i], bytes[i], hipMemcpyHostToDevice, s));
+  }
+  TriCandParams T;
+  memset(&T, 0, sizeof(T));
+  T.desc1 = (const uint32_t *)m->d_desc.p; T.ur1 = (const float *)m->d_ur.p;
+  T.desc2 = (const uint32_t *)m->d_qdesc.p; T.kp2 = (const float *)m->d_qf[0].p; T.ur2 = (const float *)m->d_qf[1].p;
+  T.hasmp2 = (const uint8_t *)m->d_qfl.p; T.node_idx2 = (const int32_t *)m->d_qi[0].p;
+  T.items = (const TriItem *)m->d_qi[1].p; T.nitems = (int)items.size();
+  for (int l = 0; l < ORBX_MAX_LEVELS; l++) T.sf2[l] = l < k2->nlevels ? k2->scale_factors[l] : 0.f;
+  T.epx = ep_x; T.epy = ep_y; T.epipole_gate = epipole_gate; T.bOnlyStereo = bOnlyStereo;
+  const size_t ni = items.size();
+  std::vector<int32_t> off(ni), cnt(ni);
+  std::vector<uint32_t> keys;
+  size_t cap = std::max<size_t>(16 * ni, 1024);
+  for (int attempt = 0; attempt < 2; attempt++) {   // the second attempt knows the exact total
+    MCHECK(m, m->scratch[0].reserve(sizeof(int32_t) * (2 * ni + 1)));
+    MCHECK(m, m->scratch[1].reserve(sizeof(uint32_t) * cap));
+    T.item_off = (int32_t *)m->scratch[0].p; T.item_cnt = T.item_off + ni; T.total = T.item_cnt + ni;
+    T.keys = (uint32_t *)m->scratch[1].p; T.cap = (int)std::min<size_t>(cap, 0x7fffffff);
+    MCHECK(m, hipMemsetAsync(T.total, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_triangulation_candidates, dim3((T.nitems + 3) / 4), dim3(256), 0, s, T);
+    MCHECK(m, hipGetLastError());
+    int32_t total = 0;
+    MCHECK(m, hipMemcpyAsync(&total, T.total, sizeof(total), hipMemcpyDeviceToHost, s));
+    MCHECK(m, hipMemcpyAsync(off.data(), T.item_off, sizeof(int32_t) * ni, hipMemcpyDeviceToHost, s));
+    MCHECK(m, hipMemcpyAsync(cnt.data(), T.item_cnt, sizeof(int32_t) * ni, hipMemcpyDeviceToHost, s));
+    MCHECK(m, hipStreamSynchronize(s));
+    if ((size_t)total <= cap) {
+      keys.resize((size_t)total);
+      if (total > 0) MCHECK(m, hipMemcpy(keys.data(), T.keys, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
+      break;
+    }
+    if (attempt == 1) { m->err = "triangulation candidates: buffer too small twice"; return ORBX_E_HIP; }
+    cap = (size_t)total;
+  }
+  // CSR over the keypoints of KF1 (a keypoint belongs to one node, i.e. to at most one item), every list ordered by key
+  for (size_t i = 0; i < ni; i++) start[(size_t)items[i].idx1 + 1] += cnt[i];
+  for (int i = 0; i < k1->n; i++) start[(size_t)i + 1] += start[(size_t)i];
+  idx2.resize(keys.size()); dist.resize(keys.size());
+  for (size_t i = 0; i < ni; i++) {
+    if (!cnt[i]) continue;
+    uint32_t *kb = keys.data() + off[i];
+    std::sort(kb, kb + cnt[i]);
+    const int o = start[(size_t)items[i].idx1];
+    for (int c = 0; c < cnt[i]; c++) {
+      idx2[(size_t)o + c] = k2->node_idx[items[i].start2 + (0xffff - (int)(kb[c] & 0xffffu))];
+      dist[(size_t)o + c] = (int32_t)(kb[c] >> 16);
+    }
+  }
+  return (int)keys.size();
+}
+
+int orbm_triangulation_candidates(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, float ep_x, float ep_y, int epipole_gate,
+                                  int bOnlyStereo, int32_t *cand_start, int32_t *cand_idx2, int32_t *cand_dist, int cap) {
+  if (!m || !k1 || !k2 || !cand_start || cap < 0 || (cap > 0 && (!cand_idx2 || !cand_dist))) return ORBX_E_ARG;
+  if (k1->n < 0 || k2->n < 0 || k2->nlevels < 1 || k2->nlevels > ORBX_MAX_LEVELS) return ORBX_E_ARG;
+  if ((k1->n > 0 && (!k1->u_right || !k1->has_mappoint)) || (k2->n > 0 && (!k2->u_right || !k2->has_mappoint))) return ORBX_E_ARG;
+  std::vector<int32_t> start, idx2, dist;
+  const int total = triangulation_candidates(m, k1, k2, ep_x, ep_y, epipole_gate, bOnlyStereo, start, idx2, dist);
+  if (total < 0) return total;
+  memcpy(cand_start, start.data(), sizeof(int32_t) * start.size());
+  if (total <= cap && total > 0) {
+    memcpy(cand_idx2, idx2.data(), sizeof(int32_t) * (size_t)total);
+    memcpy(cand_dist, dist.data(), sizeof(int32_t) * (size_t)total);
+  }
+  return total;   // > cap: nothing but cand_start was written; call again with that capacity
+}
+
+static int prune_pairs_by_rotation(const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, int32_t *matches12, int nmatches);
+
+int orbm_search_for_triangulation_pred(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, float ep_x, float ep_y, int epipole_gate,
+                                       int bOnlyStereo, int bCoarse, int checkOri, orbm_pair_predicate_t pred, void *user, int32_t *matches12) {
+  if (!m || !k1 || !k2 || !matches12 || (!pred && !bCoarse)) return ORBX_E_ARG;
+  if (k1->n < 0 || k2->n < 0 || k2->nlevels < 1 || k2->nlevels > ORBX_MAX_LEVELS) return ORBX_E_ARG;
+  if ((k1->n > 0 && (!k1->u_right || !k1->has_mappoint)) || (k2->n > 0 && (!k2->u_right || !k2->has_mappoint))) return ORBX_E_ARG;
+  for (int i = 0; i < k1->n; i++) matches12[i] = -1;
+  std::vector<int32_t> start, idx2, dist;
+  const int total = triangulation_candidates(m, k1, k2, ep_x, ep_y, epipole_gate, bOnlyStereo, start, idx2, dist);
+  if (total < 0) return total;
+  int nmatches = 0;
+  for (int i = 0; i < k1->n; i++)
+    for (int c = start[(size_t)i]; c < start[(size_t)i + 1]; c++)
+      if (bCoarse || pred(user, i, idx2[(size_t)c])) { matches12[i] = idx2[(size_t)c]; nmatches++; break; }   // :1148-1153
+  if (checkOri && nmatches > 0) nmatches = prune_pairs_by_rotation(k1, k2, matches12, nmatches);
+  return nmatches;
+}
+
 int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, const float *R1w, const float *t1w,
                                   const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
                                   int bOnlyStereo, int bCoarse, int checkOri, int32_t *matches12) {
@@ -2102,27 +2234,8 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *k1, const or
     mul33(A, R12, B);
     mul33(B, K2i, T.F12);
   }
-  // merge-walk of the two feature vectors (:1036-1188): one work item per unmatched keypoint of KF1 in a shared node
   std::vector<TriItem> items;
-  int f1 = 0, f2 = 0;
-  while (f1 < k1->n_nodes && f2 < k2->n_nodes) {
-    if (k1->node_id[f1] == k2->node_id[f2]) {
-      const int s2 = k2->node_start[f2], l2 = k2->node_start[f2 + 1] - s2;
-      if (l2 > 0xffff) { m->err = "vocabulary node with more than 65535 keypoints"; return ORBX_E_ARG; }
-      for (int i1 = k1->node_start[f1]; i1 < k1->node_start[f1 + 1]; i1++) {
-        const int idx1 = k1->node_idx[i1];
-        if (idx1 < 0 || idx1 >= k1->n) return ORBX_E_ARG;
-        if (k1->has_mappoint[idx1]) continue;                          // :1050-1055
-        if (bOnlyStereo && !(k1->u_right[idx1] >= 0)) continue;        // :1057-1061
-        if (l2 > 0) items.push_back(TriItem{idx1, s2, l2});
-      }
-      f1++; f2++;
-    } else if (k1->node_id[f1] < k2->node_id[f2]) {
-      while (f1 < k1->n_nodes && k1->node_id[f1] < k2->node_id[f2]) f1++;
-    } else {
-      while (f2 < k2->n_nodes && k2->node_id[f2] < k1->node_id[f1]) f2++;
-    }
-  }
+  { const int rc = triangulation_items(m, k1, k2, bOnlyStereo, items); if (rc < 0) return rc; }
   int nmatches = 0;
   if (!items.empty()) {
     MCHECK(m, hipSetDevice(m->device));
@@ -2151,25 +2264,29 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *k1, const or
     MCHECK(m, hipStreamSynchronize(s));
     for (int i = 0; i < k1->n; i++) nmatches += matches12[i] >= 0;
   }
-  if (checkOri && nmatches > 0) {  // :1162-1172, :1191-1207
-    std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
-    const float factor = 1.0f / ORBM_HISTO_LENGTH;
-    // the reference fills the histogram in merge-walk order; only the bin sizes matter afterwards
-    for (int i = 0; i < k1->n; i++) {
-      if (matches12[i] < 0) continue;
-      float rot = k1->keys_un[i].angle - k2->keys_un[matches12[i]].angle;
-      if ((double)rot < 0.0) rot += 360.0f;
-      int bin = (int)roundf(rot * factor);
-      if (bin == ORBM_HISTO_LENGTH) bin = 0;
-      if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(i);
-    }
-    int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
-    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
-    orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
-    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
-    }
+  if (checkOri && nmatches > 0) nmatches = prune_pairs_by_rotation(k1, k2, matches12, nmatches);
+  return nmatches;
+}
+
+// rotation-histogram pruning of SearchForTriangulation's pairs, ORBmatcher.cc:1162-1172, :1191-1207
+static int prune_pairs_by_rotation(const orbm_keyframe_t *k1, const orbm_keyframe_t *k2, int32_t *matches12, int nmatches) {
+  std::vector<std::vector<int>> rotHist(ORBM_HISTO_LENGTH);
+  const float factor = 1.0f / ORBM_HISTO_LENGTH;
+  // the reference fills the histogram in merge-walk order; only the bin sizes matter afterwards
+  for (int i = 0; i < k1->n; i++) {
+    if (matches12[i] < 0) continue;
+    float rot = k1->keys_un[i].angle - k2->keys_un[matches12[i]].angle;
+    if ((double)rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+    if (bin >= 0 && bin < ORBM_HISTO_LENGTH) rotHist[bin].push_back(i);
+  }
+  int sizes[ORBM_HISTO_LENGTH], ind1, ind2, ind3;
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+  orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+  for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
   }
   return nmatches;
 }

@@ -417,6 +417,34 @@ int orbm_search_for_triangulation(orbm_t *m, const orbm_keyframe_t *kf1, const o
                                   const float *cam1, const float *cam2, int bOnlyStereo, int bCoarse, int checkOri,
                                   int32_t *matches12);
 
+/* The same member for keyframes whose epipolar test is NOT Pinhole's: KannalaBrandt8 cameras and two-camera rigs
+ * (pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, sigma1, sigma2) is a virtual call, ORBmatcher.cc:1148;
+ * KannalaBrandt8's triangulates with cv::SVD, outside this path - SURVEY.md section 2 row 4).  The device does everything in front
+ * of the predicate, the predicate stays the caller's:
+ *
+ * orbm_triangulation_candidates: per keypoint idx1 of KF1 without a map point (and, with bOnlyStereo, with mvuRight >= 0) every
+ * keypoint idx2 of KF2 in the same vocabulary node that has no map point (:1083), passes the stereo filter (:1088-1090), lies
+ * within TH_LOW (:1096) and - when epipole_gate != 0 (the reference: !pKF1->mpCamera2) and neither keypoint is stereo - is not
+ * within 10 scaled pixels of the epipole (ep_x, ep_y) = pKF2->mpCamera->project(R2w * Cw1 + t2w) (:992, :1105-1113).
+ * CSR: cand_start[kf1->n + 1]; cand_idx2 / cand_dist[cap] hold the lists, each ordered by (distance ascending, position in
+ * the node DESCENDING): the reference keeps a running best with "dist > bestDist -> skip" and updates it on <=, so its answer is
+ * the LAST minimum among the candidates the predicate accepts = the FIRST entry of this order that it accepts.
+ * Rigs: pass u_right all negative (bStereo is false for them, :1059, :1086) and the concatenated [left; right] keypoints.
+ * Returns the total number of candidates; if it exceeds cap only cand_start was written - call again with that capacity.
+ *
+ * orbm_search_for_triangulation_pred: the whole member around a caller-supplied predicate: candidates as above, then per idx1
+ * the first listed idx2 with bCoarse || pred(user, idx1, idx2), then the rotation-histogram pruning (:1162-1172, :1191-1207).
+ * pred is called on the calling thread, only for pairs that passed every other gate, in list order, and must be pure.
+ * matches12[kf1->n] (out) = vMatches12.  Returns nmatches.  The adapter's KannalaBrandt8 / rig branch is this call with
+ * pred = the reference's own epipolarConstrain (csrc/adapter/ORBmatcher_hip.cc). */
+typedef int (*orbm_pair_predicate_t)(void *user, int idx1, int idx2);
+int orbm_triangulation_candidates(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float ep_x, float ep_y,
+                                  int epipole_gate, int bOnlyStereo, int32_t *cand_start, int32_t *cand_idx2, int32_t *cand_dist,
+                                  int cap);
+int orbm_search_for_triangulation_pred(orbm_t *m, const orbm_keyframe_t *kf1, const orbm_keyframe_t *kf2, float ep_x, float ep_y,
+                                       int epipole_gate, int bOnlyStereo, int bCoarse, int checkOri, orbm_pair_predicate_t pred,
+                                       void *user, int32_t *matches12);
+
 /* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
  *                                         vector<int> &vnMatches12, int windowSize)              (ORBmatcher.cc:722-837)
  * f1 / f2: mvKeysUn + mDescriptors of the two frames (f2 with its image bounds; u_right unused); prev_matched[2*n1]

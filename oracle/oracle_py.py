@@ -386,6 +386,56 @@ def search_for_triangulation(K1, K2, R1w, t1w, R2w, t2w, Cw1, cam1, cam2, only_s
     return n, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
 
 
+PAIR_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+def search_for_triangulation_pred(K1, K2, ep, epipole_gate, pred, only_stereo=False, coarse=False, check_ori=False):
+    """SearchForTriangulation around an injected epipolar predicate pred(idx1, idx2) -> bool (ORBmatcher.cc:1148's virtual call)."""
+    m12 = np.full(max(K1.N, 1), -1, dtype=np.int32)
+    L = lib()
+    cb = PAIR_PRED(lambda user, i1, i2: 1 if pred(i1, i2) else 0)
+    L.orc_search_for_triangulation_pred.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, PAIR_PRED, C.c_void_p, C.c_void_p]
+    n = L.orc_search_for_triangulation_pred(C.byref(K1.k), C.byref(K2.k), C.c_float(ep[0]), C.c_float(ep[1]), int(bool(epipole_gate)), int(only_stereo),
+                                            int(coarse), int(check_ori), cb, None, _p(m12))
+    m12 = m12[:K1.N]
+    i1 = np.nonzero(m12 >= 0)[0]
+    return n, np.stack([i1, m12[i1]], axis=1).astype(np.int64)
+
+
+def triangulation_candidates(K1, K2, ep, epipole_gate, only_stereo=False):
+    """(start[K1.N + 1], idx2[], dist[]): the candidate lists in front of the predicate, ordered (dist ascending, node position descending)."""
+    L = lib()
+    L.orc_triangulation_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    start = np.zeros(K1.N + 1, np.int32)
+    cap = 1 << 16
+    while True:
+        idx2, dist = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        tot = L.orc_triangulation_candidates(C.byref(K1.k), C.byref(K2.k), C.c_float(ep[0]), C.c_float(ep[1]), int(bool(epipole_gate)), int(only_stereo),
+                                             _p(start), _p(idx2), _p(dist), cap)
+        if tot <= cap:
+            return start, idx2[:tot].copy(), dist[:tot].copy()
+        cap = tot
+
+
+def pinhole_pair_geometry(R1w, t1w, R2w, t2w, Cw1, cam1, cam2):
+    """(epipole in image 2, F12) of a Pinhole keyframe pair, ORBmatcher.cc:988-1010 + Pinhole.cpp:143-148."""
+    a = lambda x: np.ascontiguousarray(x, dtype=np.float32)
+    R1w, t1w, R2w, t2w, Cw1, cam1, cam2 = a(R1w), a(t1w), a(R2w), a(t2w), a(Cw1), a(cam1), a(cam2)
+    ep, F12 = np.zeros(2, np.float32), np.zeros(9, np.float32)
+    L = lib()
+    L.orc_pinhole_pair_geometry.argtypes = [C.c_void_p] * 9
+    L.orc_pinhole_pair_geometry(_p(R1w), _p(t1w), _p(R2w), _p(t2w), _p(Cw1), _p(cam1), _p(cam2), _p(ep), _p(F12))
+    return ep, F12
+
+
+def pinhole_epipolar_constrain(F12, x1, y1, x2, y2, unc):
+    """Pinhole::epipolarConstrain (Pinhole.cpp:150-164) for one pair."""
+    L = lib()
+    L.orc_pinhole_epipolar_constrain.argtypes = [C.c_void_p] + [C.c_float] * 5
+    F12 = np.ascontiguousarray(F12, dtype=np.float32)
+    return bool(L.orc_pinhole_epipolar_constrain(_p(F12), C.c_float(x1), C.c_float(y1), C.c_float(x2), C.c_float(y2), C.c_float(unc)))
+
+
 def search_by_bow(KF, F, nnratio=0.7, check_ori=True, n_left=-1):
     """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:273-469) on two OracleKeyFrame views; n_left = F.Nleft."""
     L = lib()

@@ -1594,33 +1594,12 @@ static int epipolar_constrain(const float *F12, float x1, float y1, float x2, fl
   return (double)dsqr < 3.84 * (double)unc;
 }
 
-int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2, const float *R1w, const float *t1w,
-                                 const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
-                                 int bOnlyStereo, int bCoarse, int checkOri, int32_t *vMatches12) {
-  /* C2 = R2w*Cw+t2w; ep = project(C2), :988-994 */
-  float C2[3];
-  for (int i = 0; i < 3; i++) {
-    float t0 = R2w[i * 3 + 0] * Cw1[0] + R2w[i * 3 + 1] * Cw1[1] + R2w[i * 3 + 2] * Cw1[2];
-    C2[i] = (float)((double)t0 + (double)t2w[i]);
-  }
-  float epx, epy;
-  orc_project(0, cam2, C2[0], C2[1], C2[2], &epx, &epy);
-  /* R12 = R1w*R2w.t(); t12 = -R1w*R2w.t()*t2w+t1w, :1008-1010 */
-  float R12[9], Rm[9], t12[3];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      double sacc = 0;
-      for (int k = 0; k < 3; k++) sacc += (double)R1w[i * 3 + k] * (double)R2w[j * 3 + k];
-      R12[i * 3 + j] = (float)(sacc * 1.0);
-      Rm[i * 3 + j] = (float)(sacc * -1.0);
-    }
-  for (int i = 0; i < 3; i++) {
-    float t0 = Rm[i * 3 + 0] * t2w[0] + Rm[i * 3 + 1] * t2w[1] + Rm[i * 3 + 2] * t2w[2];
-    t12[i] = (float)((double)t0 + (double)t1w[i]);
-  }
-  float F12[9];
-  orc_pinhole_F12(R12, t12, cam1, cam2, F12);
-
+/* The member with its epipolar test abstract (ORBmatcher.cc:1148: pCamera1->epipolarConstrain(...) is a virtual call; Pinhole's is   */
+/* restated above, KannalaBrandt8's rests on cv::SVD and stays outside the oracle): pred(user, idx1, idx2).  ep = the epipole in image */
+/* 2 as the caller's camera model projects it (:992); epipole_gate = !pKF1->mpCamera2 (:1105).                                          */
+typedef int (*orc_pair_predicate)(void *user, int idx1, int idx2);
+int orc_search_for_triangulation_pred(const orc_keyframe *k1, const orc_keyframe *k2, float epx, float epy, int epipole_gate,
+                                      int bOnlyStereo, int bCoarse, int checkOri, orc_pair_predicate pred, void *user, int32_t *vMatches12) {
   int nmatches = 0;
   for (int i = 0; i < k1->N; i++) vMatches12[i] = -1;
   const int HISTO_LENGTH = 30;
@@ -1644,11 +1623,11 @@ int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2,
           if (bOnlyStereo && !bStereo2) continue;
           const int dist = orc_descriptor_distance(k1->desc + 32 * (size_t)idx1, k2->desc + 32 * (size_t)idx2);
           if (dist > 50 || dist > bestDist) continue;
-          if (!bStereo1 && !bStereo2) {
+          if (!bStereo1 && !bStereo2 && epipole_gate) {
             const float distex = epx - k2->kx[idx2], distey = epy - k2->ky[idx2];
             if (distex * distex + distey * distey < 100 * k2->scaleFactors[k2->octave[idx2]]) continue;
           }
-          if (bCoarse || epipolar_constrain(F12, k1->kx[idx1], k1->ky[idx1], k2->kx[idx2], k2->ky[idx2], k2->levelSigma2[k2->octave[idx2]])) {
+          if (pred(user, idx1, idx2) || bCoarse) {        /* :1148 (the predicate is evaluated first, as there) */
             bestIdx2 = idx2;
             bestDist = dist;
           }
@@ -1682,6 +1661,101 @@ int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2,
   }
   for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
   return nmatches;
+}
+
+/* Pinhole keyframes (mpCamera2 == NULL): the predicate is Pinhole::epipolarConstrain with the pair's F12 */
+typedef struct { const orc_keyframe *k1, *k2; float F12[9]; } pinhole_pred_ctx;
+static int pinhole_pred(void *user, int idx1, int idx2) {
+  const pinhole_pred_ctx *c = (const pinhole_pred_ctx *)user;
+  return epipolar_constrain(c->F12, c->k1->kx[idx1], c->k1->ky[idx1], c->k2->kx[idx2], c->k2->ky[idx2], c->k2->levelSigma2[c->k2->octave[idx2]]);
+}
+/* exposed for tests that inject the same predicate into the product (tests/test_gpu_triangulation_pred.py) */
+int orc_pinhole_epipolar_constrain(const float *F12, float x1, float y1, float x2, float y2, float unc) { return epipolar_constrain(F12, x1, y1, x2, y2, unc); }
+
+/* epipole and F12 of a Pinhole pair: C2 = R2w*Cw+t2w, ep = project(C2) (:988-994); R12 = R1w*R2w.t(), t12 = -R1w*R2w.t()*t2w+t1w (:1008-1010) */
+void orc_pinhole_pair_geometry(const float *R1w, const float *t1w, const float *R2w, const float *t2w, const float *Cw1, const float *cam1,
+                               const float *cam2, float *ep, float *F12) {
+  float C2[3];
+  for (int i = 0; i < 3; i++) {
+    float t0 = R2w[i * 3 + 0] * Cw1[0] + R2w[i * 3 + 1] * Cw1[1] + R2w[i * 3 + 2] * Cw1[2];
+    C2[i] = (float)((double)t0 + (double)t2w[i]);
+  }
+  orc_project(0, cam2, C2[0], C2[1], C2[2], &ep[0], &ep[1]);
+  float R12[9], Rm[9], t12[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double sacc = 0;
+      for (int k = 0; k < 3; k++) sacc += (double)R1w[i * 3 + k] * (double)R2w[j * 3 + k];
+      R12[i * 3 + j] = (float)(sacc * 1.0);
+      Rm[i * 3 + j] = (float)(sacc * -1.0);
+    }
+  for (int i = 0; i < 3; i++) {
+    float t0 = Rm[i * 3 + 0] * t2w[0] + Rm[i * 3 + 1] * t2w[1] + Rm[i * 3 + 2] * t2w[2];
+    t12[i] = (float)((double)t0 + (double)t1w[i]);
+  }
+  orc_pinhole_F12(R12, t12, cam1, cam2, F12);
+}
+
+int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2, const float *R1w, const float *t1w,
+                                 const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
+                                 int bOnlyStereo, int bCoarse, int checkOri, int32_t *vMatches12) {
+  pinhole_pred_ctx c;
+  c.k1 = k1; c.k2 = k2;
+  float ep[2];
+  orc_pinhole_pair_geometry(R1w, t1w, R2w, t2w, Cw1, cam1, cam2, ep, c.F12);
+  return orc_search_for_triangulation_pred(k1, k2, ep[0], ep[1], 1, bOnlyStereo, bCoarse, checkOri, pinhole_pred, &c, vMatches12);
+}
+
+/* The lists orbm_triangulation_candidates documents (include/orbhip.h), from the same loops: per idx1 every idx2 that reaches the   */
+/* predicate when bestDist never drops (dist <= TH_LOW and the gates), ordered (dist ascending, node position descending).            */
+int orc_triangulation_candidates(const orc_keyframe *k1, const orc_keyframe *k2, float epx, float epy, int epipole_gate, int bOnlyStereo,
+                                 int32_t *start, int32_t *cidx2, int32_t *cdist, int cap) {
+  int total = 0;
+  for (int i = 0; i <= k1->N; i++) start[i] = 0;
+  /* lists are built per idx1 in idx1 order: first the counts, then a second merge-walk that fills */
+  for (int pass = 0; pass < 2; pass++) {
+    int f1 = 0, f2 = 0;
+    while (f1 < k1->n_nodes && f2 < k2->n_nodes) {
+      if (k1->node_id[f1] == k2->node_id[f2]) {
+        for (int i1 = k1->node_start[f1]; i1 < k1->node_start[f1 + 1]; i1++) {
+          const int idx1 = k1->node_idx[i1];
+          if (k1->has_mp[idx1]) continue;
+          const int bStereo1 = k1->uRight[idx1] >= 0;
+          if (bOnlyStereo && !bStereo1) continue;
+          int n = 0;
+          for (int i2 = k2->node_start[f2]; i2 < k2->node_start[f2 + 1]; i2++) {
+            const int idx2 = k2->node_idx[i2];
+            if (k2->has_mp[idx2]) continue;
+            const int bStereo2 = k2->uRight[idx2] >= 0;
+            if (bOnlyStereo && !bStereo2) continue;
+            const int dist = orc_descriptor_distance(k1->desc + 32 * (size_t)idx1, k2->desc + 32 * (size_t)idx2);
+            if (dist > 50) continue;
+            if (!bStereo1 && !bStereo2 && epipole_gate) {
+              const float distex = epx - k2->kx[idx2], distey = epy - k2->ky[idx2];
+              if (distex * distex + distey * distey < 100 * k2->scaleFactors[k2->octave[idx2]]) continue;
+            }
+            if (pass == 1 && start[idx1] + n < cap) {   /* insertion sort by (dist asc, position desc): a later equal distance goes first */
+              int o = start[idx1] + n;
+              while (o > start[idx1] && cdist[o - 1] >= dist) { cidx2[o] = cidx2[o - 1]; cdist[o] = cdist[o - 1]; o--; }
+              cidx2[o] = idx2; cdist[o] = dist;
+            }
+            n++;
+          }
+          if (pass == 0) { start[idx1 + 1] = n; total += n; }
+        }
+        f1++; f2++;
+      } else if (k1->node_id[f1] < k2->node_id[f2]) {
+        while (f1 < k1->n_nodes && k1->node_id[f1] < k2->node_id[f2]) f1++;
+      } else {
+        while (f2 < k2->n_nodes && k2->node_id[f2] < k1->node_id[f1]) f2++;
+      }
+    }
+    if (pass == 0) {
+      for (int i = 0; i < k1->N; i++) start[i + 1] += start[i];
+      if (total > cap) return total;
+    }
+  }
+  return total;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -227,6 +227,16 @@ int orc_search_by_bow_kf_kf(const orc_keyframe *K1, const orc_keyframe *K2, floa
 int orc_search_for_triangulation(const orc_keyframe *k1, const orc_keyframe *k2, const float *R1w, const float *t1w,
                                  const float *R2w, const float *t2w, const float *Cw1, const float *cam1, const float *cam2,
                                  int bOnlyStereo, int bCoarse, int checkOri, int32_t *matches12);
+/* the same member around an injected epipolar predicate (the KannalaBrandt8 / rig call sites, ORBmatcher.cc:1148), the candidate lists
+ * in front of it, and the Pinhole pieces a test needs to inject the reference's own Pinhole predicate elsewhere */
+typedef int (*orc_pair_predicate)(void *user, int idx1, int idx2);
+int orc_search_for_triangulation_pred(const orc_keyframe *k1, const orc_keyframe *k2, float epx, float epy, int epipole_gate,
+                                      int bOnlyStereo, int bCoarse, int checkOri, orc_pair_predicate pred, void *user, int32_t *vMatches12);
+int orc_triangulation_candidates(const orc_keyframe *k1, const orc_keyframe *k2, float epx, float epy, int epipole_gate, int bOnlyStereo,
+                                 int32_t *start, int32_t *cidx2, int32_t *cdist, int cap);
+int orc_pinhole_epipolar_constrain(const float *F12, float x1, float y1, float x2, float y2, float unc);
+void orc_pinhole_pair_geometry(const float *R1w, const float *t1w, const float *R2w, const float *t2w, const float *Cw1, const float *cam1,
+                               const float *cam2, float *ep, float *F12);
 /* Pinhole::epipolarConstrain inputs: F12 = K1^-T [t12]x R12 K2^-1 (Pinhole.cpp:143-148), exported for tests. */
 void orc_pinhole_F12(const float *R12, const float *t12, const float *cam1, const float *cam2, float *F12);
 

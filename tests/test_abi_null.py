@@ -19,6 +19,8 @@ def test_null_arguments_do_not_crash():
             for t in fn.argtypes:
                 if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
                     args.append(None)
+                elif isinstance(t, type) and issubclass(t, C._CFuncPtr):
+                    args.append(t())          # a NULL function pointer (orbm_pair_predicate_t)
                 elif t in (C.c_float, C.c_double):
                     args.append(0.0)
                 else:
