@@ -30,7 +30,7 @@ E_EMPTY, E_ARG, E_HIP, E_CAP = -1, -2, -3, -4
 ABI_SYMBOLS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
-    "orbx_extract_batch_device", "orbx_get_host_us", "orbx_level_info", "orbx_download_level", "orbx_download_blurred_level",
+    "orbx_extract_batch_device", "orbx_get_host_us", "orbx_level_info", "orbx_download_level", "orbx_download_pyramid", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
@@ -103,6 +103,7 @@ def load(build_if_needed=True):
     L.orbx_get_host_us.argtypes = [vp, vp, i32]
     L.orbx_level_info.argtypes = [vp, i32, vp, vp]
     L.orbx_download_level.argtypes = [vp, i32, i32, i32, vp, sz]
+    L.orbx_download_pyramid.argtypes = [vp, i32, i32, vp, sz, vp, vp]
     L.orbx_download_blurred_level.argtypes = [vp, i32, i32, vp, sz]
     L.orbx_download_candidates.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_download_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
@@ -272,10 +273,13 @@ class ORBextractor:
         kps = np.zeros(cap, dtype=KP_DTYPE)
         desc = np.zeros((cap, 32), dtype=np.uint8)
         n = C.c_int(0)
+        # the C call alone (what a C++ caller of the adapter pays), for tools/run_sequence.py.  The argument objects are made BEFORE the
+        # clock starts: an allocation inside the timed region can start CPython's full garbage collection, which takes ~40 ms once a
+        # large package such as PyTorch is imported - that was the "36 ms stall" of round 2's sequence runs (tools/stall_probe.py)
+        args = (self.h, _p(image), rows, cols, C.c_size_t(image.strides[0]), int(vLappingArea[0]), int(vLappingArea[1]), _p(kps), _p(desc), cap, C.byref(n))
         t0 = time.perf_counter()
-        rc = self.L.orbx_extract(self.h, _p(image), rows, cols, C.c_size_t(image.strides[0]), int(vLappingArea[0]),
-                                 int(vLappingArea[1]), _p(kps), _p(desc), cap, C.byref(n))
-        self.last_call_s = time.perf_counter() - t0   # the C call alone (what a C++ caller of the adapter pays), for tools/run_sequence.py
+        rc = self.L.orbx_extract(*args)
+        self.last_call_s = time.perf_counter() - t0
         if rc == E_EMPTY:
             return -1, kps[:0], desc[:0]
         if rc == E_CAP:
@@ -360,6 +364,19 @@ class ORBextractor:
         r, c = self.level_shape(level)
         out = np.zeros((r + 2 * border, c + 2 * border), dtype=np.uint8)
         self._check(self.L.orbx_download_level(self.h, frame, level, border, _p(out), C.c_size_t(out.strides[0])), "orbx_download_level")
+        return out
+
+    def image_pyramid(self, frame=0, border=0):
+        """mvImagePyramid of one frame in one transfer (orbx_download_pyramid): list of per-level arrays incl. the border frame."""
+        off = np.zeros(self.nlevels, np.uint64); st = np.zeros(self.nlevels, np.uint64)
+        nbytes = self._check(self.L.orbx_download_pyramid(self.h, int(frame), int(border), None, 0, _p(off), _p(st)), "orbx_download_pyramid")
+        buf = np.zeros(max(nbytes, 1), np.uint8)
+        self._check(self.L.orbx_download_pyramid(self.h, int(frame), int(border), _p(buf), C.c_size_t(buf.size), _p(off), _p(st)), "orbx_download_pyramid")
+        out = []
+        for l in range(self.nlevels):
+            r, c = self.level_shape(l)
+            rows, stride = r + 2 * border, int(st[l])
+            out.append(buf[int(off[l]):int(off[l]) + rows * stride].reshape(rows, stride)[:, :c + 2 * border])
         return out
 
     def blurred_level(self, level, frame=0):
@@ -496,12 +513,11 @@ class ORBmatcher:
         fs = frame.struct()
         moq = np.full(nq, -1, dtype=np.int32)
         bd = np.full(nq, 256, dtype=np.int32)
+        args = (self.m, C.byref(fs), C.byref(qs), C.c_float(self.mfNNratio if nnratio is None else nnratio),
+                int(self.TH_HIGH if th_dist is None else th_dist), int(bool(use_second)), _p(frame.slot), _p(frame.slot_obs), _p(moq), _p(bd))
         t0 = time.perf_counter()
-        rc = self.L.orbm_search_by_projection(self.m, C.byref(fs), C.byref(qs),
-                                              C.c_float(self.mfNNratio if nnratio is None else nnratio),
-                                              int(self.TH_HIGH if th_dist is None else th_dist), int(bool(use_second)),
-                                              _p(frame.slot), _p(frame.slot_obs), _p(moq), _p(bd))
-        self.last_call_s = time.perf_counter() - t0   # the C call alone, for tools/run_sequence.py
+        rc = self.L.orbm_search_by_projection(*args)
+        self.last_call_s = time.perf_counter() - t0   # the C call alone (arguments made before the clock starts, see ORBextractor.__call__)
         self._check(rc, "orbm_search_by_projection")
         if rc < 0:
             raise OrbError("orbm_search_by_projection rc=%d" % rc)

@@ -34,16 +34,25 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 #define PROF_DEPTH 32   // batches whose stage events are kept for orbx_get_stage_ms / orbm_get_stage_ms (averaged)
 
+// ORBHIP_TRACE_ALLOC=1: every growth of a device / pinned buffer is reported on stderr with the time its free and its allocation took
+// (diagnostic: a re-allocation inside the per-frame path is a latency spike of tens of milliseconds)
+static bool trace_alloc() { static const bool on = getenv("ORBHIP_TRACE_ALLOC") != nullptr; return on; }
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
   hipError_t reserve(size_t need) {
     if (need <= bytes) return hipSuccess;
+    const double t0 = trace_alloc() ? wall_ms() : 0.0;
     if (p) (void)hipFree(p);
+    const double t1 = trace_alloc() ? wall_ms() : 0.0;
     p = nullptr;
+    const size_t old = bytes;
     bytes = 0;
     hipError_t e = hipMalloc(&p, need);
     if (e == hipSuccess) bytes = need;
+    if (trace_alloc()) fprintf(stderr, "orbhip-alloc: device buffer %zu -> %zu bytes: hipFree %.3f ms, hipMalloc %.3f ms\n", old, need, t1 - t0, wall_ms() - t1);
     return e;
   }
   void release() {
@@ -94,6 +103,7 @@ struct orbx_handle {
   // pinned host staging of the single-frame entry point (orbx_extract): pageable copies would serialise on HIP's own staging
   void *pin_in = nullptr, *pin_out = nullptr;
   size_t pin_in_bytes = 0, pin_out_bytes = 0;
+  DevBuf d_pyrpack; void *pin_pyr = nullptr; size_t pin_pyr_bytes = 0;   // orbx_download_pyramid: bordered levels, packed
   // the per-frame sequence of orbx_extract (H2D, 5 launches, 1 D2H) captured once per configuration as a hipGraph:
   // one submission per frame instead of 7
   hipGraphExec_t graph = nullptr;
@@ -259,6 +269,8 @@ void orbx_destroy(orbx_t *h) {
   if (h->graph) (void)hipGraphExecDestroy(h->graph);
   if (h->last_done) (void)hipEventDestroy(h->last_done);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_pyr) (void)hipHostFree(h->pin_pyr);
+  h->d_pyrpack.release();
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->ev_ok)
     for (auto &set : h->ev)
@@ -967,6 +979,60 @@ int orbx_download_level(orbx_t *h, int frame, int level, int border, uint8_t *ds
   if (level == 0)
     return download_plane(h, h->last.img0 + (size_t)frame * h->last.img0_frame_stride, h->last.img0_stride, G.w, G.h, border, dst, dst_stride);
   return download_plane(h, h->last.pyr + (size_t)frame * h->last.pyr_fs + G.off, (size_t)G.pitch, G.w, G.h, border, dst, dst_stride);
+}
+
+// mvImagePyramid of one frame in ONE transfer: every level with its BORDER_REFLECT_101 frame (ORBextractor.cc:1203-1215) is
+// written by one kernel into a packed device buffer, copied once into pinned memory and from there into the caller's block.
+struct PackLevel { const uint8_t *src; int spitch, w, h, dstride; unsigned doff, dbytes; };
+struct PackParams { PackLevel L[ORBX_MAX_LEVELS]; int nlevels, border; uint8_t *dst; };
+}  // extern "C"
+__global__ __launch_bounds__(256) void k_pyramid_pack(PackParams P) {
+  const PackLevel G = P.L[blockIdx.y];
+  auto refl = [](int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+  };
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < G.dbytes; i += gridDim.x * 256u) {
+    const int y = (int)(i / (unsigned)G.dstride) - P.border, x = (int)(i % (unsigned)G.dstride) - P.border;
+    P.dst[G.doff + i] = G.src[(size_t)refl(y, G.h) * G.spitch + refl(x, G.w)];
+  }
+}
+extern "C" {
+int orbx_download_pyramid(orbx_t *h, int frame, int border, uint8_t *dst, size_t dst_bytes, size_t *offsets, size_t *strides) {
+  if (!h || !h->have_last || frame < 0 || frame >= h->last.nframes || border < 0 || border > 64 || !offsets || !strides) return ORBX_E_ARG;
+  XCHECK(h, hipSetDevice(h->device));
+  PackParams P;
+  memset(&P, 0, sizeof(P));
+  P.nlevels = h->nlevels; P.border = border;
+  size_t total = 0;
+  for (int l = 0; l < h->nlevels; l++) {
+    const LevelGeom &G = h->geom[l];
+    PackLevel &L = P.L[l];
+    L.src = l == 0 ? h->last.img0 + (size_t)frame * h->last.img0_frame_stride : h->last.pyr + (size_t)frame * h->last.pyr_fs + G.off;
+    L.spitch = l == 0 ? (int)h->last.img0_stride : G.pitch;
+    L.w = G.w; L.h = G.h; L.dstride = G.w + 2 * border;
+    L.doff = (unsigned)total; L.dbytes = (unsigned)((size_t)L.dstride * (size_t)(G.h + 2 * border));
+    offsets[l] = total; strides[l] = (size_t)L.dstride;
+    total += ((size_t)L.dbytes + 63) & ~(size_t)63;
+  }
+  if (!dst) return (int)std::min<size_t>(total, 0x7fffffff);   // size query
+  if (dst_bytes < total) return ORBX_E_CAP;
+  XCHECK(h, h->d_pyrpack.reserve(total));
+  if (h->pin_pyr_bytes < total) {
+    if (h->pin_pyr) (void)hipHostFree(h->pin_pyr);
+    h->pin_pyr = nullptr; h->pin_pyr_bytes = 0;
+    XCHECK(h, hipHostMalloc(&h->pin_pyr, total, hipHostMallocDefault));
+    h->pin_pyr_bytes = total;
+  }
+  P.dst = (uint8_t *)h->d_pyrpack.p;
+  if (h->last_pending) XCHECK(h, hipStreamWaitEvent(h->stream, h->last_done, 0));
+  hipLaunchKernelGGL(k_pyramid_pack, dim3(64, h->nlevels), dim3(256), 0, h->stream, P);
+  XCHECK(h, hipGetLastError());
+  XCHECK(h, hipMemcpyAsync(h->pin_pyr, h->d_pyrpack.p, total, hipMemcpyDeviceToHost, h->stream));
+  XCHECK(h, hipStreamSynchronize(h->stream));
+  memcpy(dst, h->pin_pyr, total);
+  return (int)std::min<size_t>(total, 0x7fffffff);
 }
 
 int orbx_download_blurred_level(orbx_t *h, int frame, int level, uint8_t *dst, size_t dst_stride) {

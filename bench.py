@@ -10,8 +10,8 @@ Workloads (`--config`):
          from KannalaBrandt8::project with the TUM_512.yaml:9-19 parameters, th 15; map points resident in HBM.
 
 A batch = B frames that are already resident in HBM: 11 extraction launches + the search launches on one stream.  A STEP =
-`--batches-per-step` batches (default 48 x 256 = 12288 frames per GPU), dealt round-robin to `--streams` independent pipelines, so
-that the driver's 20-step run keeps the GPU busy for well over a second.  The batches of a step cycle through `--groups` different
+`--batches-per-step` batches (default 224 x 256 = 57344 frames per GPU, ~0.3 s), dealt round-robin to `--streams` independent pipelines,
+so that the driver's 20-step run keeps the GPU busy for more than six seconds (its utilisation sampler looks every five).  The batches of a step cycle through `--groups` different
 frame sets (2048 distinct frames per GPU by default).
 
 One process per GPU; frames shard across ranks with no data-path collective, so scaling is weak: every rank runs
@@ -27,8 +27,9 @@ Extra keys on the JSON line:
                    (non-zero exit status on any mismatch)
   cpu_baseline     the CPU oracle (oracle/, kind "port") timed natively on this host per BASELINE.md section 3: one core and all
                    cores (one frame per thread), median and mean, extract / match split (rank 0, N=1 only)
-  host_fed         the same pipeline fed from pinned host memory (H2D double-buffered on a copy stream, D2H of counts, keypoints,
-                   descriptors and match indices): frames/s and PCIe GB/s.  `value` stays the HBM-resident rate.
+  host_fed         the same pipeline fed from pinned host memory (all frame sets in turn; H2D on a copy stream ahead of the pipelines, D2H
+                   of counts, keypoints, descriptors and match indices), on EVERY rank, MAX time over ranks: whole-job frames/s and PCIe
+                   GB/s per GPU; the downloaded outputs of every pipeline are compared with a resident run.  `value` stays the HBM-resident rate.
 """
 import argparse
 import importlib
@@ -68,7 +69,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="euroc")
     ap.add_argument("--batch", type=int, default=256, help="frames per batch (one launch sequence)")
-    ap.add_argument("--batches-per-step", type=int, default=48, help="batches per step: a step is batch * batches_per_step frames per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=224, help="batches per step: a step is batch * batches_per_step frames per GPU")
     ap.add_argument("--groups", type=int, default=8, help="distinct frame sets of `batch` frames resident in HBM")
     ap.add_argument("--streams", type=int, default=4, help="independent pipelines on separate HIP streams (batches alternate)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (also skips verified_frames)")
@@ -206,10 +207,14 @@ def main():
     if selftest:
         shard.init_distributed(backend if backend != "nccl" else "gloo")
         dt = shard.timed_steps(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, world=world)
+        hf = None
+        if not args.no_host_fed:   # the host-fed leg's plumbing: every rank runs it, MAX over ranks, whole-job aggregate
+            tf = shard.timed_steps(lambda: time.sleep(0.003 * (rank + 1)), 1, 0, world=world)
+            hf = {"value": round(world * 48 * B / tf, 2), "unit": "frames/s", "n_gpus": world, "seconds_max_over_ranks": round(tf, 5)}
         if rank == 0:
             print(json.dumps({"selftest": True, "metric": conf["metric"], "value": round(shard.aggregate_fps(frames_per_step, args.steps, world, dt), 2),
                               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                              "scaling": "weak", "data": "none (ORB_BENCH_SELFTEST: no device work, launcher / barrier / MAX plumbing only)"}))
+                              "scaling": "weak", "host_fed": hf, "data": "none (ORB_BENCH_SELFTEST: no device work, launcher / barrier / MAX plumbing only)"}))
         shard.finish_distributed()
         return
 
@@ -241,6 +246,8 @@ def main():
         def __init__(self):
             self.ex = pkg.ORBextractor(device=dev_index, **CFG)
             self.mt = pkg.ORBmatcher(0.8 if not tumvi else 0.9, True, device=dev_index)
+            if not tumvi:
+                self.mt.set_scan_mode(1)      # the caller knows its windows cover the frame: no grid-window walk launch (it would only vote and leave)
             self.cap = cap = self.ex.configure(H, W, B)
             self.stream = torch.cuda.Stream(device=dev)
             # slot 0 = the last frame of the set (query side of pair 0); slots 1..B = the set's frames
@@ -389,10 +396,12 @@ def main():
         pp.ex.set_profiling(False)
         pp.mt.set_profiling(False)
 
-    # ---- host-fed: frames in pinned host memory, H2D on copy streams double-buffered against compute, results back to pinned memory
+    # ---- host-fed: frames in pinned host memory, H2D on a copy stream ahead of the pipelines, results back to pinned memory.
+    # EVERY rank runs it (on a multi-GPU node this is the figure PCIe / NUMA / host DRAM can bend); bracketed like the timed
+    # region (barrier + device sync on both sides), MAX over ranks, aggregate = world * frames / max time.
     host_fed = None
-    if rank == 0 and world == 1 and not args.no_host_fed:
-        h_img = torch.from_numpy(groups[0][0]).pin_memory()
+    if not args.no_host_fed:
+        h_img = [torch.from_numpy(groups[g][0]).pin_memory() for g in range(G)]      # all G frame sets cycle through the link
         NS = 6                                  # staging buffers: uploads run up to six batches ahead of the pipelines
         stage = [torch.empty_like(d_img[0]) for _ in range(NS)]
         # ONE upload stream and ONE download stream: uploads run back to back at the link's full rate (two uploads in flight would
@@ -403,21 +412,23 @@ def main():
                       nm=torch.empty((B,), dtype=torch.int32).pin_memory()) for _ in range(S)]
         stage_free, pipe_done = [None] * NS, [None] * S
         up_events = []
+        last_group = [0] * S
 
         def fed_batch(k):
-            j, i = k % NS, k % S
+            j, i, g = k % NS, k % S, k % G
             pp = pipes[i]
+            last_group[i] = g
             with torch.cuda.stream(up_stream):
                 if stage_free[j] is not None:
                     up_stream.wait_event(stage_free[j])     # the batch that read this staging buffer in place has finished
                 u0 = torch.cuda.Event(enable_timing=True); u0.record(up_stream)
-                stage[j].copy_(h_img, non_blocking=True)
+                stage[j].copy_(h_img[g], non_blocking=True)
                 up = torch.cuda.Event(enable_timing=True); up.record(up_stream)
                 up_events.append((u0, up))
             pp.stream.wait_event(up)
             if pipe_done[i] is not None:
                 pp.stream.wait_event(pipe_done[i])          # the pipeline's previous outputs have been downloaded
-            pp.batch(0, images=stage[j], scene=scene_dev)
+            pp.batch(g, images=stage[j], scene=scene_dev)
             stage_free[j] = pp.stream.record_event()
             with torch.cuda.stream(down_stream):
                 down_stream.wait_event(stage_free[j])
@@ -434,21 +445,51 @@ def main():
         torch.cuda.synchronize()
         nfed = 48
         up_events.clear()
-        t0 = time.perf_counter()
-        for k in range(nfed):
-            fed_batch(k)
-        torch.cuda.synchronize()
-        tf = time.perf_counter() - t0
+        counter_k = [0]
+
+        def fed_step():
+            for _ in range(nfed):
+                fed_batch(counter_k[0])
+                counter_k[0] += 1
+
+        tf = shard.timed_steps(fed_step, 1, 0, sync=torch.cuda.synchronize, world=world, device=dev if backend == "nccl" else None)
         up_b = H * W
         down_b = 8 + cap * (28 + 32) + (0 if args.no_match else cap * 4 + 4)
-        ffps = nfed * B / tf
-        same = bool(torch.equal(h_out[0]["cnt"], pipes[0].d_cnt[1:].cpu()))
+        ffps = world * nfed * B / tf
         up_ms = float(np.mean([a.elapsed_time(b) for a, b in up_events]))
-        host_fed = {"value": round(ffps, 2), "unit": "frames/s", "batches": nfed, "staging_buffers": NS, "pipelines": S,
-                    "pcie_bytes_per_frame": {"h2d": up_b, "d2h": down_b}, "pcie_GBps": round(ffps * (up_b + down_b) / 1e9, 2),
-                    "h2d_GBps": round(ffps * up_b / 1e9, 2), "upload_ms_per_batch": round(up_ms, 3),
+        # what came back over the link against a resident run of the same frame set on the same pipeline: counts, keypoints,
+        # descriptors and match indices of every frame
+        same = True
+        for i, pp in enumerate(pipes):
+            pp.batch(last_group[i], scene=scene_dev)
+            torch.cuda.synchronize()
+            cnt_d = pp.d_cnt[1:].cpu()
+            same = same and bool(torch.equal(h_out[i]["cnt"], cnt_d))
+            nn = cnt_d[:, 0].clamp(max=cap)
+            live = (torch.arange(cap)[None, :] < nn[:, None])
+            same = same and bool(torch.equal(h_out[i]["kps"].view(torch.int32)[live], pp.d_kps[1:].cpu().view(torch.int32)[live]))
+            same = same and bool(torch.equal(h_out[i]["desc"][live], pp.d_desc[1:].cpu()[live]))
+            if not args.no_match:
+                same = same and bool(torch.equal(h_out[i]["nm"], pp.d_nm.cpu()))
+                if tumvi:
+                    same = same and bool(torch.equal(h_out[i]["moq"][live], pp.d_slot.cpu()[live]))
+                else:     # match_of_query is indexed by the PREVIOUS frame's keypoints (frame p - 1, wrapping)
+                    nq = torch.roll(nn, 1)
+                    liveq = (torch.arange(cap)[None, :] < nq[:, None])
+                    same = same and bool(torch.equal(h_out[i]["moq"][liveq], pp.d_moq.cpu()[liveq]))
+        if world > 1:
+            import torch.distributed as dist
+            tsame = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tsame, op=dist.ReduceOp.MIN)
+            same = bool(tsame.item())
+        host_fed = {"value": round(ffps, 2), "unit": "frames/s", "n_gpus": world, "batches_per_rank": nfed, "distinct_frame_sets": G, "staging_buffers": NS, "pipelines": S,
+                    "pcie_bytes_per_frame": {"h2d": up_b, "d2h": down_b}, "pcie_GBps_per_gpu": round(ffps / world * (up_b + down_b) / 1e9, 2),
+                    "h2d_GBps_per_gpu": round(ffps / world * up_b / 1e9, 2), "upload_ms_per_batch": round(up_ms, 3),
                     "upload_GBps_while_copying": round(B * up_b / (up_ms * 1e-3) / 1e9, 2), "pcie_spec_GBps": PCIE_SPEC_GBS, "outputs_equal_resident_run": same,
-                    "note": "pinned host frames -> HBM on one upload stream into %d staging buffers, %d pipelines; counts, keypoints, descriptors, match indices back to pinned memory on a download stream" % (NS, S)}
+                    "note": "every rank: pinned host frames (all %d frame sets in turn) -> HBM on one upload stream into %d staging buffers, %d pipelines; counts, keypoints, "
+                            "descriptors, match indices back to pinned memory on a download stream; MAX time over ranks; outputs compared with a resident run, every frame" % (G, NS, S)}
+        if not same:
+            sys.stderr.write("bench.py: rank %d: host-fed outputs differ from the resident run\n" % rank)
 
     # ---- roofline of the dominant KERNEL (per launch).  Stage -> kernel: "pyramid" is nlevels-1 launches of k_resize.
     stage_bytes = algorithmic_bytes(level_shapes, n_kp)
@@ -526,6 +567,8 @@ def main():
             out["roofline"]["valu_issue"] = valu
         if host_fed is not None:
             out["host_fed"] = host_fed
+            if not host_fed["outputs_equal_resident_run"]:
+                rc = 4
         if gpu_last is not None:
             nthreads = host_cores()
             cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=(EUROC_K, EUROC_D) if distort else None)

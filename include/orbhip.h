@@ -92,6 +92,12 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
  * border = 19 (EDGE_THRESHOLD) also synthesises the BORDER_REFLECT_101 frame of ORBextractor.cc:1203-1215. */
 int orbx_level_info(const orbx_t *h, int level, int *rows, int *cols);
 int orbx_download_level(orbx_t *h, int frame, int level, int border, uint8_t *dst, size_t dst_stride);
+/* All levels of one frame at once, each with its `border`-pixel BORDER_REFLECT_101 frame, packed into dst: level l starts at
+ * dst + offsets[l] with strides[l] bytes per row (offsets / strides: nlevels entries, written by the call).  One kernel, one
+ * device-to-host copy, one synchronisation - what the extractor adapter uses to fill mvImagePyramid when a caller still reads
+ * it on the host (the reference's own Frame::ComputeStereoMatches).  dst == NULL: only offsets / strides and the size.
+ * Returns the number of bytes (ORBX_E_CAP if dst_bytes is smaller). */
+int orbx_download_pyramid(orbx_t *h, int frame, int border, uint8_t *dst, size_t dst_bytes, size_t *offsets, size_t *strides);
 
 /* Stage taps for parity tests (same data the pipeline consumes; host pointers, synchronous).  Valid after an
  * extract call, for frame index `frame` of that call. */

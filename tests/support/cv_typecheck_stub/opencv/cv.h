@@ -23,6 +23,7 @@ struct Mat {
   size_t step;
   Mat();
   Mat(int r, int c, int type);
+  Mat(int r, int c, int type, void *data, size_t step);
   int type() const;
   bool empty() const;
   Mat rowRange(int a, int b) const;

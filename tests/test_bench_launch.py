@@ -29,7 +29,18 @@ def test_gpus_2_spawns_two_ranks():
     # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 2 ms
     assert out["ms_per_step"] >= 4.0
     # whole-job value: both ranks' frames over the max time
-    assert abs(out["value"] - 2 * 256 * 48 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-3   # default step: 48 batches of 256 frames
+    assert abs(out["value"] - 2 * 256 * 224 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-3   # default step: 224 batches of 256 frames
+    # the host-fed leg runs on every rank as well: MAX over ranks (rank 1 sleeps 6 ms, rank 0 3 ms), whole-job aggregate
+    hf = out["host_fed"]
+    assert hf["n_gpus"] == 2 and hf["seconds_max_over_ranks"] >= 0.006
+    assert abs(hf["value"] - 2 * 48 * 256 / hf["seconds_max_over_ranks"]) / hf["value"] < 1e-2
+
+
+def test_no_host_fed_flag():
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--no-host-fed"], {})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["host_fed"] is None
 
 
 def test_gpus_1_is_a_single_process():

@@ -57,6 +57,12 @@ def test_pyramid_border(ex, oex, oracle, frame):
         import ctypes as C
         oracle.lib().orc_copy_make_border101(pyr[l].ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), ref.ctypes.data_as(C.c_void_p), 19, C.c_size_t(w + 38))
         assert np.array_equal(ex.image_pyramid_level(l, border=19), ref)
+    # every level in one transfer (orbx_download_pyramid: what the adapter fills mvImagePyramid from)
+    for border in (19, 0):
+        packed = ex.image_pyramid(border=border)
+        assert len(packed) == len(pyr)
+        for l in range(len(pyr)):
+            assert np.array_equal(packed[l], ex.image_pyramid_level(l, border=border)), "level %d border %d" % (l, border)
 
 
 @pytest.mark.parametrize("seed", [1000, 1001, 1002, 1003, 1004])
