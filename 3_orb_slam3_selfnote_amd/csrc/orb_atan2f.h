@@ -7,7 +7,7 @@
 // of atan(0.5), atan(1), atan(1.5), atan(inf)); x86-64 has no FMA / ifunc variant of these two, so every operation is
 // a plain IEEE-754 single add / mul / div in source order and host and gfx950 agree bit for bit when nothing is
 // contracted (-ffp-contract=off, correctly rounded fp32 division).
-// tests/test_atan2f.py checks the replica against the host libm: atanf over every float (ORB_EXHAUSTIVE=1) or a
+// tests/test_libm_replicas.py checks the replica against the host libm: atanf over every float (ORB_EXHAUSTIVE=1) or a
 // strided sample, atan2f on the quadrant / zero / infinity cases and on random pairs.
 #pragma once
 #include <stdint.h>

@@ -53,8 +53,14 @@ __device__ __forceinline__ void dev_project(int cam_type, const float *p, float 
     const float psi = orbat::ref_atan2f(Y, X);
     const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
     const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+#ifdef ORB_KB8_DOUBLE_TRIG   // see orbm_project (orbhip.hip).  The device's fp64 cos / sin are ROCm's, within 1 ulp of glibc's but NOT verified equal:
+                             // with this switch the windows of config 5 are no longer covered by the bit-exact replicas (parity unpinned)
+    u = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
+    v = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+#else
     u = p[0] * r * orbsc::ref_cosf(psi) + p[2];   // cos / sin on a float: the <math.h> overloads -> cosf / sinf (libm choices)
     v = p[1] * r * orbsc::ref_sinf(psi) + p[3];
+#endif
   }
 }
 

@@ -657,7 +657,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   if (prof) XCHECK(h, hipEventRecord(pev[3], s));
   hipLaunchKernelGGL(k_blur, dim3(h->totalTiles * nframes), dim3(256), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[4], s));
-  hipLaunchKernelGGL(k_describe, dim3(((h->totalKp + 3) / 4) * nframes), dim3(256), 0, s, P);   // also writes the frame totals
+  hipLaunchKernelGGL(k_describe, dim3(std::max((h->totalKp + 3) / 4, 1) * nframes), dim3(256), 0, s, P);   // also writes the frame totals (>= 1 workgroup per frame: nfeatures == 0)
   if (prof) { XCHECK(h, hipEventRecord(pev[5], s)); h->prof_head++; h->stage_valid = true; }
   XCHECK(h, hipGetLastError());
   h->last = P;
@@ -1294,8 +1294,13 @@ void orbm_project(int cam_type, const float *p, float X, float Y, float Z, float
     // cos / sin on a float resolve to the float overloads (cosf / sinf) once <math.h> is in the translation unit, which
     // opencv2/opencv.hpp brings (libm choices) - the same assumption MapPoint::PredictScale's log(float) rests on;
     // evaluated through the bit-exact glibc replicas the device uses (tests/test_libm_replicas.py: equal to the host libm)
+#ifdef ORB_KB8_DOUBLE_TRIG   // build switch for reference builds in which cos(psi) / sin(psi) bind ::cos(double) (GCC 5, or no <math.h> wrapper)
+    *u = (float)((double)(p[0] * r) * ::cos((double)psi) + (double)p[2]);
+    *v = (float)((double)(p[1] * r) * ::sin((double)psi) + (double)p[3]);
+#else
     *u = p[0] * r * orbsc::ref_cosf(psi) + p[2];
     *v = p[1] * r * orbsc::ref_sinf(psi) + p[3];
+#endif
   }
 }
 
