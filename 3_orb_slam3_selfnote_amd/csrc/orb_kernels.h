@@ -5,7 +5,7 @@
 //   k_pyramid_chain K1  the same planes in ONE launch for single-frame calls (a tile recomputes the levels below it in LDS)
 //   k_fast      K2  FAST-9/16 score + per-cell NMS, cell detected at iniThFAST and again at minThFAST if empty, one workgroup per 30-px cell
 //   k_octree    K3  DistributeOctTree, one workgroup per (frame, level), node list in LDS
-//   k_blur      K5  7x7 sigma-2 fixed-point Gaussian, 128x32 tiles staged through LDS
+//   k_blur      K5  7x7 sigma-2 fixed-point Gaussian as two int8 MFMA products, 128x32 tiles staged through LDS
 //   k_describe  K4+K6+K7  IC_Angle + steered BRIEF + lapping-order scatter + frame totals, one wavefront (64 lanes) per keypoint
 // All arithmetic is integer or non-contracted IEEE fp32/fp64 (hipcc -ffp-contract=off) so results are bit-exact
 // against the CPU restatement the tests use.  No MFMA: this is byte/bit work bound by HBM, LDS and VALU integer rate.
@@ -946,20 +946,59 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K5: cv::GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101, 8U fixed point: taps {18,34,49,55,49,34,18},
-// row sums exact in 16 bits, (sum + 32768) >> 16 after the column pass.  64x16 output tile per workgroup.
+// K5: cv::GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101, 8U fixed point: taps {18,34,49,55,49,34,18} - on the matrix pipe.
+// The 8-bit GaussianBlur is an exact integer computation - row sums of at most 257 * 255 (16 bits, no rounding), then
+// (sum of 7 weighted row sums + 32768) >> 16 - i.e. two products with banded constant matrices:
+//     T = I H      (H[k][x] = tap[k - x - 13]: 64 input columns -> 32 output columns)
+//     O = V T      (V[y][k] = tap[k - y]:      64 rows of T     -> 32 output rows)
+// v_mfma_i32_32x32x32_i8 takes SIGNED bytes, so pixels enter as I - 128 (one xor per dword) with the correction 128 * 257 in the
+// accumulator seed, and the 16-bit row sums are split into their high and low byte (again minus 128) for the second product:
+//     sum V T = 256 (sum V hi' ) + (sum V lo') + 257 * 128 * 257.
+// The accumulator of the first product (row index in the registers, column on the lane) IS the B operand of the second one - the
+// guide's "accumulator tile as the next MFMA's operand": element j of lane half h is row (j & 3) + 8 (j >> 2) + 4 h, and V's
+// fragments are laid out in that order - so nothing moves between the passes but the byte split.  Per 32 x 32 outputs: 4 + 4
+// MFMAs and about 130 vector instructions per wavefront for the arithmetic (the v_dot4 / v_dot2 form of rounds 1-2: 220), and with
+// the border tiles loaded by LDS-DMA like the interior ones (half of all tiles touch an edge; their byte-wise loops were a third
+// of the old kernel's instructions) 0.247 -> 0.172 ms per 256 frames, byte for byte the same planes.
+// Workgroup = the same 128 x 32 tile as before, wavefront w its columns 32 w .. 32 w + 31; the results go through a 4 KB LDS
+// image so that the stores are 16-byte row segments.
 // ------------------------------------------------------------------------------------------------------------
+// per lane (column / row n = lane & 31, half h = lane >> 5): H fragments of K-steps 0, 1, then V fragments of K-steps 0, 1
+struct BlurTab { uint32_t v[64][16]; };
+constexpr uint32_t blur_tap(int d) { return d == 0 || d == 6 ? 18u : d == 1 || d == 5 ? 34u : d == 2 || d == 4 ? 49u : d == 3 ? 55u : 0u; }
+constexpr BlurTab make_blur_tab() {
+  BlurTab t{};
+  for (int lane = 0; lane < 64; lane++) {
+    const int n = lane & 31, h = lane >> 5;
+    for (int s = 0; s < 2; s++)
+      for (int d = 0; d < 4; d++) {
+        uint32_t hv = 0, vv = 0;
+        for (int b = 0; b < 4; b++) {
+          const int j = 4 * d + b;
+          hv |= blur_tap(32 * s + 16 * h + j - n - 13) << (8 * b);                       // H[k = 32 s + 16 h + j][n]: input column k -> output column n
+          vv |= blur_tap(32 * s + (j & 3) + 8 * (j >> 2) + 4 * h - n) << (8 * b);        // V[m = n][k = 32 s + rho(h, j)]: row sum k -> output row m
+        }
+        t.v[lane][4 * s + d] = hv;
+        t.v[lane][8 + 4 * s + d] = vv;
+      }
+  }
+  return t;
+}
+__device__ const BlurTab g_blurTab = make_blur_tab();
+
 #define BLUR_TX 128
 #define BLUR_TY 32
-#define BLUR_IN_PITCH 36   // dwords per input tile row
-__global__ __launch_bounds__(256) void k_blur(FrameParams P) {
-  // input tile: rows y0-3 .. y0+34 (38), columns x0-4 .. x0+131 (136 B = 34 dwords); row sums: 38 x 128 u16
-  __shared__ __align__(16) uint32_t sIn[38 * BLUR_IN_PITCH];   // 144-byte rows = nine 16-byte LDS-DMA chunks (136 bytes are used)
-  __shared__ __align__(16) uint32_t sRow[19 * 128];  // vertical pairs of row sums: [row pair][column]
-  const int tid = threadIdx.x;
+#define BLURM_PITCH 176          // bytes per input tile row: 160 used (columns x0 - 16 .. x0 + 143) + one 16-byte chunk of padding
+                                 // (44 dwords: 16 consecutive rows start in 16 different 4-bank groups, the A fragments read conflict-free)
+#define BLURM_OPITCH 144         // bytes per output staging row
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(FrameParams P) {   // 60 VGPRs: the tile load is one HBM latency per workgroup, hidden only by resident workgroups
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef int v16i __attribute__((ext_vector_type(16)));
+  __shared__ __align__(16) uint8_t sIn[64 * BLURM_PITCH];   // rows y0 - 3 .. y0 + 34 are filled; 38 .. 63 only feed zero taps
+  __shared__ __align__(16) uint8_t sOut[32 * BLURM_OPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int tile, frame;
   xcd_map(P.totalTiles, P.magicTiles, P.nframes, frame, tile);
-  // tile record (orbx_configure): origin, level size and plane offsets in one 32-byte scalar load
   const uint4 t0 = reinterpret_cast<const uint4 *>(P.tiles)[2 * tile], t1 = reinterpret_cast<const uint4 *>(P.tiles)[2 * tile + 1];
   const int x0 = (int)(t0.x & 0xffffu), y0 = (int)(t0.x >> 16), level = (int)t0.y;
   struct { int w, h, bpitch; size_t boff; } G;
@@ -970,23 +1009,37 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
   if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
   else { pitch = (int)(t0.w & 0xffffu); img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)t1.y << 32) | t1.x); }
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
-  // interior tiles (the majority): no reflection anywhere, plain coalesced dword rows.  Decided once per workgroup.
-  const bool interior = aligned && x0 >= 4 && x0 + BLUR_TX + 12 <= G.w && y0 >= 3 && y0 + BLUR_TY + 3 <= G.h;   // + 12: the 144-byte rows
-  if (interior) {
-    // LDS-DMA: 38 rows x 9 chunks of 16 bytes, lane-linear, straight into the tile (idx / 9 as (idx * 7282) >> 16, exact
-    // below 342).  The ninth chunk reaches 8 bytes past column x0 + 131: still inside the row (see `interior`).
-    const uint8_t *base = img + (size_t)(y0 - 3) * pitch + (x0 - 4);
-    for (int idx = tid; idx < 38 * 9; idx += 256) {
-      const uint32_t r = mul24((uint32_t)idx, 7282u) >> 16, c = (uint32_t)idx - 9u * r;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (mul24(r, (uint32_t)pitch) + 16u * c)),
-                                       (__attribute__((address_space(3))) void *)(reinterpret_cast<uint8_t *>(sIn) + idx * 16), 16, 0, 0);
+  // ---- input tile: 38 rows x 11 chunks of 16 bytes from column x0 - 16, by LDS-DMA for EVERY tile of a level that is larger than
+  // the halo: BORDER_REFLECT_101 across the top / bottom edge is a source ROW (an address), across the left / right edge it is at
+  // most three bytes per row, which a few threads copy inside the tile once the DMA has landed.  Chunks that would start outside
+  // the row's memory are fetched from a clamped address (their bytes never meet a non-zero tap of a stored output, except the
+  // reflected ones).  Tiny levels and unaligned level-0 images take the byte-wise loop.
+  const int wlim = level == 0 ? G.w : pitch;                 // bytes of a row that may be read (level 0 is the caller's image: not past its rows)
+  const bool dma = aligned && G.w >= 160 && G.h >= 40 && (wlim & 15) == 0;
+  const bool edgeL = x0 == 0, edgeR = x0 + 131 >= G.w;       // some stored output of this tile needs a column left of 0 / right of w - 1
+  if (dma) {
+    for (int idx = tid; idx < 38 * 11; idx += 256) {
+      const uint32_t r = mul24((uint32_t)idx, 5958u) >> 16, c = (uint32_t)idx - 11u * r;      // idx / 11, exact below 418
+      int yy = y0 - 3 + (int)r;
+      yy = yy < 0 ? -yy : yy;
+      yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy;
+      int xb = x0 - 16 + 16 * (int)c;
+      xb = min(max(xb, 0), wlim - 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (mul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)xb)),
+                                       (__attribute__((address_space(3))) void *)(sIn + idx * 16), 16, 0, 0);
+    }
+    if (edgeL || edgeR) {
+      __syncthreads();                                        // the tile has landed (the compiler drains the DMA in front of the barrier)
+      if (tid < 38 * 6) {
+        const int r = tid / 6, k = tid - 6 * r;
+        const int x = k < 3 ? -1 - k : G.w + (k - 3);         // the column to synthesise
+        const int xs = k < 3 ? 1 + k : G.w - 2 - (k - 3);     // its BORDER_REFLECT_101 source
+        const bool need = k < 3 ? edgeL : (edgeR && x - (x0 - 16) < 160);
+        if (need) sIn[r * BLURM_PITCH + (x - (x0 - 16))] = sIn[r * BLURM_PITCH + (xs - (x0 - 16))];
+      }
     }
   } else {
-    // border tiles: one reflection step is enough whenever the level is larger than the halo (always, except degenerate
-    // configurations, which take the general loop); columns far beyond the right edge only feed outputs nobody stores.
-    // Two loops: the dwords that lie inside the image row are plain aligned loads from the (row-reflected) source row;
-    // the few dword columns that touch the left or right image edge - cE of the 34, typically 1 or 5 - are visited by a
-    // second, short loop.  In one loop every wavefront would pay for the byte-wise reflection (each holds an edge dword).
+    // byte-wise loop.  Only columns x0 - 3 .. x0 + 130 meet non-zero taps.
     const bool small = G.w < 16 || G.h < 16;
     auto srcRow = [&](int r) {
       int yy = y0 + r - 3;
@@ -994,102 +1047,81 @@ __global__ __launch_bounds__(256) void k_blur(FrameParams P) {
       else { yy = yy < 0 ? -yy : yy; yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy; yy = max(yy, 0); }
       return img + mul24((uint32_t)yy, (uint32_t)pitch);
     };
-    // plain columns: xb = x0 - 4 + 4c with 0 <= xb and xb + 3 < w  <=>  cL <= c < cR
-    const int cL = aligned ? (x0 >= 4 ? 0 : 1) : 34;
-    const int cR = aligned ? min(34, max(cL, (G.w - x0 + 4) >> 2)) : 34;   // first c with xb + 3 >= w
-    const int cE = cL + (34 - cR);
-    for (int idx = tid; idx < 38 * 34; idx += 256) {
-      const uint32_t r = mul24((uint32_t)idx, 1928u) >> 16, c = (uint32_t)idx - r * 34u;
-      if ((int)c >= cL && (int)c < cR) sIn[r * BLUR_IN_PITCH + c] = *reinterpret_cast<const uint32_t *>(srcRow((int)r) + (x0 - 4 + 4 * (int)c));
-    }
-    const float inv_cE = 1.0f / (float)max(cE, 1);
-    for (int j = tid; j < 38 * cE; j += 256) {
-      const int r = (int)(((float)j + 0.5f) * inv_cE), k = j - r * cE;   // exact: j < 1292, see k_resize
-      const int c = k < cL ? k : cR + (k - cL);
-      const int xb = x0 - 4 + 4 * c;
-      const uint8_t *row = srcRow(r);
+    for (int idx = tid; idx < 38 * 36; idx += 256) {          // dword columns 3 .. 38 of the 40: bytes x0 - 4 .. x0 + 139
+      const uint32_t r = mul24((uint32_t)idx, 1821u) >> 16, c = 3u + ((uint32_t)idx - r * 36u);   // idx / 36, exact below 1368
+      const int xb = x0 - 16 + 4 * (int)c;
+      const uint8_t *row = srcRow((int)r);
       uint32_t v;
-      if (small) {
-        v = (uint32_t)row[reflect101(xb, G.w)] | ((uint32_t)row[reflect101(xb + 1, G.w)] << 8) |
-            ((uint32_t)row[reflect101(xb + 2, G.w)] << 16) | ((uint32_t)row[reflect101(xb + 3, G.w)] << 24);
-      } else {
+      if (aligned && xb >= 0 && xb + 3 < G.w) v = *reinterpret_cast<const uint32_t *>(row + xb);
+      else {
         v = 0;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
           int xx = xb + kk;
-          xx = xx < 0 ? -xx : xx;
-          xx = xx >= G.w ? 2 * (G.w - 1) - xx : xx;
-          xx = max(xx, 0);                      // only for columns >= w + w - 1: never part of a stored output
+          if (small) xx = reflect101(xx, G.w);
+          else { xx = xx < 0 ? -xx : xx; xx = xx >= G.w ? 2 * (G.w - 1) - xx : xx; xx = max(xx, 0); }   // beyond w + w - 1: never under a stored output
           v |= (uint32_t)row[xx] << (8 * kk);
         }
       }
-      sIn[r * BLUR_IN_PITCH + c] = v;
+      *reinterpret_cast<uint32_t *>(sIn + r * BLURM_PITCH + 4u * c) = v;
     }
   }
-  __syncthreads();
-  // horizontal pass: task = 4 consecutive outputs of TWO vertically adjacent rows; taps as two byte-quads for
-  // v_dot4_u32_u8.  The row sums (<= 257*255 = 65535: exact in 16 bits) are stored as vertical pairs
-  // (row 2k | row 2k+1 << 16) per column, which is what the vertical pass's v_dot2_u32_u16 consumes.
-  const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
-  auto hsum4 = [&](const uint32_t *row, uint32_t (&o)[4]) {
-    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
-    // output k (x = x0+4q+k) uses bytes [1+k, 7+k] of the 12-byte window d0|d1|d2
-    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
-    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
-    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
-    o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
-  };
-  for (int idx = tid; idx < 19 * 32; idx += 256) {
-    const int rp = idx >> 5, q = idx & 31;
-    uint32_t sa[4], sb[4];
-    hsum4(&sIn[(2 * rp) * BLUR_IN_PITCH + q], sa);
-    hsum4(&sIn[(2 * rp + 1) * BLUR_IN_PITCH + q], sb);
-    *reinterpret_cast<uint4 *>(&sRow[rp * 128 + 4 * q]) = make_uint4(sa[0] | (sb[0] << 16), sa[1] | (sb[1] << 16), sa[2] | (sb[2] << 16), sa[3] | (sb[3] << 16));
-  }
-  __syncthreads();
-  // vertical pass: thread = 4 columns x 4 rows; the 10-row window = 5 row pairs per column, read once (5 x b128).
-  // Output row y0+4rg+rr uses tile rows 4rg+rr .. +6: even rr take the stored pairs, odd rr the pairs shifted by one row
-  // (v_alignbit); 4 x v_dot2_u32_u16 per output, the rounding constant rides in the accumulator.
+  // ---- constant operands of this lane: H (B of the first product), V (A of the second), in the operands' element order (g_blurTab)
+  const int n = lane & 31, hh = lane >> 5;
+  v4i Hb[2], Va[2];
   {
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const int q = tid & 31, rg = tid >> 5;  // column quad 0..31, row group 0..7
-    uint4 RP[5];
+    const uint4 *tab = reinterpret_cast<const uint4 *>(g_blurTab.v[lane]);
+    const uint4 q0 = tab[0], q1 = tab[1], q2 = tab[2], q3 = tab[3];
+    Hb[0] = v4i{(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w}; Hb[1] = v4i{(int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+    Va[0] = v4i{(int)q2.x, (int)q2.y, (int)q2.z, (int)q2.w}; Va[1] = v4i{(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
+  }
+  __syncthreads();
+  // ---- T = I H for the two 32-row halves of the tile's 64 rows, seeded with 128 * 257 so that the accumulators are the row sums
+  v16i cT, cZ, cL;
 #pragma unroll
-    for (int j = 0; j < 5; j++) RP[j] = *reinterpret_cast<const uint4 *>(&sRow[(rg * 2 + j) * 128 + 4 * q]);
-    const us2 K01 = {18, 34}, K23 = {49, 55}, K45 = {49, 34}, K6 = {18, 0};
-    auto d2 = [](uint32_t a, us2 k, uint32_t acc) { return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), k, acc, false); };
-    uint32_t px[4][4];  // [row][column]
+  for (int j = 0; j < 16; j++) { cT[j] = 128 * 257; cZ[j] = 0; cL[j] = 257 * 128 * 257 + 32768; }
+  v4i Bhi[2], Blo[2];
 #pragma unroll
-    for (int cc = 0; cc < 4; cc++) {
-      uint32_t p[5];
+  for (int mt = 0; mt < 2; mt++) {
+    v16i acc = cT;
 #pragma unroll
-      for (int j = 0; j < 5; j++) p[j] = cc == 0 ? RP[j].x : cc == 1 ? RP[j].y : cc == 2 ? RP[j].z : RP[j].w;
-      uint32_t qv[5];
-#pragma unroll
-      for (int j = 0; j < 4; j++) qv[j] = __builtin_amdgcn_alignbit(p[j + 1], p[j], 16);  // (row 2j+1, row 2j+2)
-      qv[4] = p[4] >> 16;
-      const uint32_t v0 = d2(p[3], K6, d2(p[2], K45, d2(p[1], K23, d2(p[0], K01, 32768u))));
-      const uint32_t v1 = d2(qv[3], K6, d2(qv[2], K45, d2(qv[1], K23, d2(qv[0], K01, 32768u))));
-      const uint32_t v2 = d2(p[4], K6, d2(p[3], K45, d2(p[2], K23, d2(p[1], K01, 32768u))));
-      const uint32_t v3 = d2(qv[4], K6, d2(qv[3], K45, d2(qv[2], K23, d2(qv[1], K01, 32768u))));
-      px[0][cc] = v0; px[1][cc] = v1; px[2][cc] = v2; px[3][cc] = v3;   // results in the high halves (0..257)
+    for (int s = 0; s < 2; s++) {
+      v4i a = *reinterpret_cast<const v4i *>(sIn + (32 * mt + n) * BLURM_PITCH + 32 * wid + 32 * s + 16 * hh);
+      a[0] ^= (int)0x80808080; a[1] ^= (int)0x80808080; a[2] ^= (int)0x80808080; a[3] ^= (int)0x80808080;
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Hb[s], acc, 0, 0, 0);
     }
-    uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff;
-    // (v >> 16) clamped to 255 and packed four to a dword: the high halves of two sums side by side (v_perm_b32), both
-    // saturated to bytes at once (v_sat_pk_u8_i16), two such pairs joined - 5 instructions per dword instead of 11
-    auto sat2 = [](uint32_t lo, uint32_t hi) {
-      uint32_t r;
-      asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_amdgcn_perm(hi, lo, 0x07060302u)));
-      return r;
-    };
+    // row sums 0 .. 65535 -> (high byte - 128, low byte - 128) as the second product's B fragments (element j = register j)
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const int y = y0 + rg * 4 + rr, x = x0 + 4 * q;
-      if (y < G.h) {
-        uint8_t *o = out + (size_t)y * G.bpitch + x;
-        const uint32_t packed = sat2(px[rr][0], px[rr][1]) | (sat2(px[rr][2], px[rr][3]) << 16);
-        if (x + 3 < G.w) *reinterpret_cast<uint32_t *>(o) = packed;
-        else for (int cc = 0; cc < 4 && x + cc < G.w; cc++) o[cc] = (uint8_t)(packed >> (8 * cc));
+    for (int d = 0; d < 4; d++) {
+      const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 1], (uint32_t)acc[4 * d], 0x05010400u);   // lo0 lo1 hi0 hi1
+      const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 3], (uint32_t)acc[4 * d + 2], 0x05010400u);
+      Blo[mt][d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+      Bhi[mt][d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u);
+    }
+  }
+  // ---- O = V T: high and low bytes separately
+  v16i aH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], Bhi[0], cZ, 0, 0, 0);
+  v16i aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], Blo[0], cL, 0, 0, 0);
+  aH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], Bhi[1], aH, 0, 0, 0);
+  aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], Blo[1], aL, 0, 0, 0);
+  // (256 aH + aL) >> 16, saturated to a byte; register j is output row rho(h, j), the lane's column is 32 w + n
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t v = ((uint32_t)aH[j] << 8) + (uint32_t)aL[j];
+    const uint32_t b = min(v >> 16, 255u);
+    sOut[((j & 3) + 8 * (j >> 2) + 4 * hh) * BLURM_OPITCH + 32 * wid + n] = (uint8_t)b;
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 3, seg = tid & 7;
+    const int y = y0 + row, x = x0 + 16 * seg;
+    if (y < G.h && x < G.w) {
+      uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)y * G.bpitch + x;
+      const uint4 v = *reinterpret_cast<const uint4 *>(sOut + row * BLURM_OPITCH + 16 * seg);
+      if (x + 16 <= G.bpitch) *reinterpret_cast<uint4 *>(out) = v;
+      else {
+        const uint8_t *b = sOut + row * BLURM_OPITCH + 16 * seg;
+        for (int cc = 0; cc < 16 && x + cc < G.w; cc++) out[cc] = b[cc];
       }
     }
   }

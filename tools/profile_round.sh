@@ -3,7 +3,7 @@
 # vector-issue calibration -> gpurun_out/<tag>_*  (copy what is to be kept into profiles/).
 set -e
 R=$PWD
-T=${1:-r02}
+T=${1:-r03}
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 echo "bench euroc done"

@@ -21,9 +21,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-         "--cuda-device-only", "-S"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "--cuda-device-only", "-S"]
 KERNELS = {"k_resize": r"^_Z8k_resize", "k_fast": r"^_Z6k_fast", "k_octree": r"^_Z8k_octreeILi256ELb1E", "k_blur": r"^_Z6k_blur",
-           "k_describe": r"^_Z10k_describe", "k_match_scan": r"^_Z12k_match_scanI5Key32Li0E", "k_match_walk": r"^_Z12k_match_walkI5Key32Li0E", "k_match_resolve": r"^_Z15k_match_resolveI5Key32Lb1E",
+           "k_describe": r"^_Z10k_describe", "k_match_scan": r"^_Z12k_match_scanI5Key32Li0E", "k_match_walk": r"^_Z12k_match_walkI5Key32Li0E", "k_match_resolve": r"^_Z15k_match_resolveI5Key32Lb1ELb1EE", "k_match_scan_mfma": r"^_Z17k_match_scan_mfma", "k_match_rank": r"^_Z12k_match_rank",
            "k_lastframe_project": r"^_Z19k_lastframe_project", "k_rot_prune": r"^_Z11k_rot_prune"}
 # opcode (suffix-stripped) -> name of the calibration class that measured it
 CLASS_OF = {
