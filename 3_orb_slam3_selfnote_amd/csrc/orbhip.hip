@@ -1402,11 +1402,15 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   }
 #undef LAUNCH_WALK
   uint32_t *rec = mfma ? (uint32_t *)m->d_rank.p : nullptr, *keyrec = mfma ? rec + nrank : nullptr, *pairflag = mfma ? keyrec + nrank : nullptr;
+  // Engine 2 (fused): the pairs k_match_rank flags make their lists inside k_match_resolve; what is left (pairs with windowed queries)
+  // goes to the walk / the vector-ALU scan.  k_match_scan_mfma is not launched then: a launch whose workgroups only read a flag and
+  // leave still queues for the kernel's registers and LDS on every CU (0.32 ms average residence beside three other pipelines).
   if (mfma) {
     hipLaunchKernelGGL(k_match_rank, dim3(npairs), dim3(MF_NT), 0, s, M, rec, keyrec, pairflag, fused ? 1 : 0);
-    hipLaunchKernelGGL(k_match_scan_mfma, dim3(sgrid.x), dim3(MF_NT), 0, s, M, (uint32_t *)m->d_topk.p, (const uint32_t *)rec, (const uint32_t *)keyrec, (const uint32_t *)pairflag);
+    if (!fused)
+      hipLaunchKernelGGL(k_match_scan_mfma, dim3(sgrid.x), dim3(MF_NT), 0, s, M, (uint32_t *)m->d_topk.p, (const uint32_t *)rec, (const uint32_t *)keyrec, (const uint32_t *)pairflag);
   }
-  const int mf = mfma ? 1 : 0;
+  const int mf = mfma && !fused ? 1 : 0;
 #define LAUNCH_MATCH(KT, LC)                                                                                              \
   do {                                                                                                                    \
     if (force == SCAN_WALK) {}                                                                                            \
