@@ -1295,6 +1295,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         const uint4 *qp = reinterpret_cast<const uint4 *>(M.qdesc + (qo + q) * 32);
         const uint4 a = qp[0], b = qp[1];
         qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+        // FUSED: no scan kernel has looked at this query's window.  A query in view whose window lies outside the grid
+        // (GetFeaturesInArea's early returns, Frame.cc:757-777) has no candidates: it is not a request (the pair's vote counts only
+        // queries with a window INSIDE the grid as live, so such a query does not keep the pair from being fused)
+        if (FUSED && fusedPair && !load_query(M, qo, q).live) myfl &= ~1u;
       }
       // my list as the rounds need it: keypoint index per entry (n = the dummy for an empty entry), validity mask,
       // octaves, and the lower bound every unlisted candidate obeys (entry capm1, the last one the list can hold)

@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def random_image(rng, H, W, synth):
@@ -340,6 +341,68 @@ def fuzz_stereo(pkg, oracle, synth, rng, log, cache):
         exL.close(); exR.close()
 
 
+def fuzz_batch_open(pkg, oracle, synth, rng, log, cache):
+    """Batch launches of the window search (orbm_search_by_projection_batch_device) with 9-14 frame pairs: most pairs search
+    open windows (the matrix-pipe scan / the fused resolve, orbm_set_hamming_engine 1 / 2), some are windowed, partly windowed or
+    dead; random keypoint subsets, duplicated descriptors, pre-occupied keypoints, keypoints outside the grid, query flags,
+    thresholds, bounds.  One engine per case (drawn), every pair against the oracle's in-order loop."""
+    import test_gpu_mfma as T
+    if "frames" not in cache:
+        fuzz_match(pkg, oracle, synth, np.random.default_rng(0), log, cache)
+    (k0, d0), (k1, d1) = cache["frames"]
+    sf, offs = cache["sf"], cache["offs"]
+    npairs = int(rng.integers(9, 15))
+    kc_all, bounds, D = random_geometry(pkg, oracle, rng, k1)
+    kq_all = pkg.undistort_keypoints(k0, EUROC_K, D)
+    cand, qry = [], []
+    for p in range(npairs):
+        nc = int(rng.choice([1, 17, 33, 200, 640, len(k1), len(k1), len(k1)]))
+        sel = np.sort(rng.choice(len(k1), nc, replace=False))
+        kc, dc = kc_all[sel].copy(), d1[sel].copy()
+        if rng.random() < 0.5 and nc > 20:
+            dup = rng.random(nc) < 0.4
+            dc[dup] = dc[rng.integers(0, nc, int(dup.sum()))]
+        if rng.random() < 0.3 and nc > 8:
+            out = rng.choice(nc, 3, replace=False)
+            kc["x"][out] = np.float32(bounds[0] - 30.0)
+        c = T.free_frame(kc, dc)
+        occ = rng.random(nc) < rng.choice([0.0, 0.2, 0.6])
+        c["slot"][occ] = 1 << 20
+        c["sobs"][occ] = rng.random(int(occ.sum())) < 0.6
+        cand.append(c)
+        nq = int(rng.choice([1, 40, 256, 257, 600, len(k0), len(k0)]))
+        qs = rng.choice(len(k0), nq, replace=rng.random() < 0.3)
+        q = T.open_queries(kq_all[qs], d0[qs].copy(), (offs[0][0] - offs[1][0], offs[0][1] - offs[1][1]))
+        q["u"] = (q["u"] + rng.normal(0, 2, nq)).astype(np.float32)
+        inv = (rng.random(nq) < 0.93).astype(np.uint8); obs = (rng.random(nq) < rng.choice([1.0, 0.7])).astype(np.uint8)
+        q["flags"] = (inv | (obs << 1)).astype(np.uint8)
+        kind = rng.random()
+        if kind < 0.15:                                   # the whole pair windowed
+            q["r"][:] = rng.choice([10.0, 25.0, 60.0]); lvl = kq_all[qs]["octave"].astype(np.int32); q["lo"] = lvl - 1; q["hi"] = lvl + 1
+        elif kind < 0.3 and nq > 10:                      # a few windowed queries: their block is not open
+            w = rng.choice(nq, max(1, nq // 20), replace=False)
+            q["r"][w] = 30.0; q["lo"][w] = 0; q["hi"][w] = 4
+        elif kind < 0.4:                                  # a smaller radius that still covers the grid for most queries only
+            q["r"][:] = 1200.0
+        qry.append(q)
+    nnratio, th, second = float(rng.choice([0.6, 0.8, 1.0])), int(rng.choice([40, 100, 255])), bool(rng.integers(0, 2))
+    engine = int(rng.integers(0, 3))
+    ref = [T.oracle_pair(oracle, c, q, bounds, sf, nnratio, th, second) for c, q in zip(cand, qry)]
+    m = pkg.ORBmatcher(nnratio, True)
+    try:
+        m.set_hamming_engine(engine)
+        got = T.run_batch(pkg, m, cand, qry, bounds, nnratio, th, second)
+    finally:
+        m.close()
+    ok = True
+    for p, (g, r) in enumerate(zip(got, ref)):
+        if not (g[0] == r[0] and np.array_equal(g[1], r[1]) and np.array_equal(g[2], r[2]) and np.array_equal(g[3], r[3]) and np.array_equal(g[4], r[4])):
+            ok = False
+            log("BATCH MISMATCH engine=%d pair %d of %d n=%d nq=%d nnratio=%s th=%d second=%s n=%d/%d" % (engine, p, npairs, len(cand[p]["k"]), len(qry[p]["u"]), nnratio, th, second, g[0], r[0]))
+    cache.setdefault("stats", {}).setdefault("batch_matches", []).append(int(np.mean([r[0] for r in ref])))
+    return ok
+
+
 def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), first=0, verbose=False):
     """Cases first .. first+n-1 of stream `seed`; every case draws from its own generator, so one case can be replayed alone."""
     bad, cache, t0 = 0, {}, time.time()
@@ -353,9 +416,10 @@ def run(pkg, oracle, synth, n, seed, log=lambda msg: print(msg, flush=True), fir
             ok4 = fuzz_reuse(pkg, oracle, synth, np.random.default_rng([seed, i, 3]), log, cache)
             ok5 = fuzz_bow_and_triangulation(pkg, oracle, synth, np.random.default_rng([seed, i, 4]), log, cache)
             ok6 = fuzz_stereo(pkg, oracle, synth, np.random.default_rng([seed, i, 5]), log, cache)
-            if not (ok1 and ok2 and ok3 and ok4 and ok5 and ok6):
+            ok7 = fuzz_batch_open(pkg, oracle, synth, np.random.default_rng([seed, i, 6]), log, cache)
+            if not (ok1 and ok2 and ok3 and ok4 and ok5 and ok6 and ok7):
                 log("   ^ case %d of seed %d" % (i, seed))
-            bad += (not ok1) + (not ok2) + (not ok3) + (not ok4) + (not ok5) + (not ok6)
+            bad += (not ok1) + (not ok2) + (not ok3) + (not ok4) + (not ok5) + (not ok6) + (not ok7)
             if (i + 1 - first) % 20 == 0:
                 log("%d / %d cases, %d mismatches, %.0f s" % (i + 1 - first, n, bad, time.time() - t0))
     finally:
@@ -379,7 +443,7 @@ def main():
     synth = importlib.import_module("3_orb_slam3_selfnote_amd.synth")
     from oracle import oracle_py as oracle   # the checker
     bad = run(pkg, oracle, synth, args.n, args.seed, first=args.first, verbose=args.verbose)
-    print("fuzz: %d cases each of: extractor configuration, window search, last-frame search, handle reuse, BoW x2 + triangulation, stereo matches; %d mismatches" % (args.n, bad))
+    print("fuzz: %d cases each of: extractor configuration, window search, last-frame search, handle reuse, BoW x2 + triangulation, stereo matches, batch search (all three Hamming engines); %d mismatches" % (args.n, bad))
     sys.exit(1 if bad else 0)
 
 

@@ -193,3 +193,23 @@ def test_2048_keypoints(pkg, oracle, synth):
                         flags=np.full(nq, 3, np.uint8)))
     check(pkg, oracle, cand[:12], qry[:12], bounds, sf, nnratio=0.7, th=60, min_total=2000)
     check(pkg, oracle, cand[12:] * 3, qry[12:] * 3, bounds, sf, nnratio=0.7, th=60, min_total=100)
+
+
+def test_in_view_queries_whose_window_is_outside_the_grid(pkg, oracle, stream):
+    """A query that is in view but whose window lies beyond the grid (Frame::GetFeaturesInArea's early returns, Frame.cc:757-777: a
+    projection far outside the image) has no candidates.  It does not keep its frame pair from being fused (the vote counts queries
+    with a window inside the grid), so the fused resolve itself must treat it as dead - found by tests/fuzz_parity.py with th 255,
+    where such a query otherwise takes a keypoint."""
+    ext, offs, sf = stream
+    bounds = (-179.5, 909.66, -101.45, 593.57)
+    cand = [free_frame(*ext[p + 1]) for p in range(12)]
+    qry = []
+    for p in range(12):
+        q = open_queries(ext[p][0], ext[p][1], (offs[p][0] - offs[p + 1][0], offs[p][1] - offs[p + 1][1]))
+        far = np.arange(7, len(q["u"]), 53)
+        q["u"] = q["u"].copy(); q["v"] = q["v"].copy()
+        q["u"][far] = np.float32(25581.0); q["v"][far[::2]] = np.float32(-17992.0)
+        qry.append(q)
+    for th in (255, 100):
+        ref = check(pkg, oracle, cand, qry, bounds, sf, nnratio=0.6, th=th, second=False)
+        assert all((r[1][np.arange(7, len(r[1]), 53)] == -1).all() for r in ref)
