@@ -94,6 +94,8 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t u) {
   asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "s"(u), "v"(a));
   return d;
 }
+// both operands per lane; the caller guarantees 24 bits
+__device__ __forceinline__ uint32_t mul24_vv(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += dpp_or_zero<0x111, 0xf>(v);
@@ -155,7 +157,7 @@ __device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
 // output quad hit LDS instead of issuing 16 global byte loads (the first version was load-issue bound).
 #define RESIZE_ROWS 8
 #define RESIZE_MAXSRC 16   // source rows per tile: floor(1.2*(RESIZE_ROWS-1)) + 2 with margin (scale <= 1.6 supported)
-__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes) {
+__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes, int tPitch) {
   extern __shared__ __align__(16) uint8_t smem_rs[];
   const LevelGeom G = P.geom[level];
   const LevelGeom Gs = P.geom[level - 1];
@@ -226,38 +228,73 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   // q / qw in float: (q + 0.5) / qw is at least 0.5 / qw >= 2^-11 away from an integer, the product's rounding error is
   // below 2^-19 for q < 8 * 1024, so truncation gives the exact quotient (four full-rate operations)
   const float inv_qw = 1.0f / (float)qw;
-  // The row loop is instantiated twice so that the source gathers are ds_read_u8 (LDS) or global_load_ubyte; one loop
-  // with a run-time pointer select compiles to FLAT loads that wait on both counters.
-  auto rows = [&](auto srcRow, auto lds) {
-    // LDS rows: column w exists (the rows are padded to 16-byte chunks) and is only ever read with weight a1 = 0 (the table clamps
-    // sx to w - 1 with fx = 0 there), so the second tap is the byte next to the first - an address offset, not a second address
-    constexpr bool LDSROWS = decltype(lds)::value;
+  if (nsrc <= RESIZE_MAXSRC) {
+    // Two passes, because the horizontal interpolation of a source row is shared by the two output rows that straddle it: the one-pass
+    // form evaluates it twice per output pixel, here it is evaluated once per (source row, output column) - about 1.4 per output pixel
+    // for 8-row tiles at scale 1.2 - and the vertical pass reads four finished values with one 8-byte LDS load.
+    // Pass 1: T[r][c] = (S[r][sx] * a0 + S[r][sx + 1] * a1) >> 4, at most 255 * 2048 / 16 = 32640: 16 bits.  Thread = output column,
+    // loop over the staged source rows: the column's table entry is read once.  Column sx + 1 = w exists in the LDS rows (they are
+    // padded to 16-byte chunks) and is only ever read with weight a1 = 0 (the table clamps sx to w - 1 with fx = 0 there).
+    uint8_t *sT = sRows + (size_t)RESIZE_MAXSRC * smemRowBytes;     // [nsrc][tPitch] bytes, u16 entries
+    for (int c = tid; c < wq; c += 256) {
+      const int2 xt = sX[c];
+      const uint32_t a0 = (uint32_t)xt.y & 0xffffu, a1 = (uint32_t)xt.y >> 16;
+      const uint8_t *sp = sRows + xt.x;
+      uint8_t *tp = sT + 2 * c;
+#pragma unroll 4
+      for (int r = 0; r < nsrc; r++) {
+        const uint32_t v = mul24_vv((uint32_t)sp[0], a0) + mul24_vv((uint32_t)sp[1], a1);
+        *reinterpret_cast<uint16_t *>(tp) = (uint16_t)(v >> 4);
+        sp += smemRowBytes;
+        tp += tPitch;
+      }
+    }
+    __syncthreads();
+    // Pass 2: thread = 4 consecutive output pixels of one row.  No saturate_cast needed: the coefficients are non-negative and each
+    // pair sums to 2048, so v is a convex combination of four bytes, rounded down-ish: always inside [0, 255].
     for (int q = tid; q < qw * nrows; q += 256) {
       const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
       const int2 yt = sY[ry];
       const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
-      const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
-      const auto S0 = srcRow(sy0), S1 = srcRow(sy1);
+      const uint32_t b0 = (uint32_t)yt.y & 0xffffu, b1 = (uint32_t)yt.y >> 16;
+      const uint2 t0 = *reinterpret_cast<const uint2 *>(sT + mul24((uint32_t)(sy0 - syFirst), (uint32_t)tPitch) + 8 * (dx0 >> 2));
+      const uint2 t1 = *reinterpret_cast<const uint2 *>(sT + mul24((uint32_t)(sy1 - syFirst), (uint32_t)tPitch) + 8 * (dx0 >> 2));
+      const uint32_t u0[4] = {t0.x & 0xffffu, t0.x >> 16, t0.y & 0xffffu, t0.y >> 16};
+      const uint32_t u1[4] = {t1.x & 0xffffu, t1.x >> 16, t1.y & 0xffffu, t1.y >> 16};
       uint32_t packed = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int2 xt = sX[dx0 + j];            // columns past the row end repeat the last one (padded table); only [0, w) is stored
-        const int sx = xt.x, sx1 = LDSROWS ? sx + 1 : min(sx + 1, Gs.w - 1);
-        const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
-        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-        // no saturate_cast needed: the coefficients are non-negative and each pair sums to 2048, so v is a convex
-        // combination of four bytes, rounded down-ish: always inside [0, 255]
-        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)v << (8 * j);
+        const uint32_t v = ((mul24_vv(b0, u0[j]) >> 16) + (mul24_vv(b1, u1[j]) >> 16) + 2) >> 2;
+        packed |= v << (8 * j);
       }
       uint8_t *dst = dstplane + mul24((uint32_t)dy, (uint32_t)G.pitch);
       if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
       else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
     }
-  };
-  if (nsrc <= RESIZE_MAXSRC) rows([&](int sy) { return smem_rs + sRowsOff + mul24((uint32_t)(sy - syFirst), (uint32_t)smemRowBytes); }, std::true_type());
-  else rows([&](int sy) { return src + mul24((uint32_t)sy, (uint32_t)spitch); }, std::false_type());  // extreme scale factors: straight from global
+    return;
+  }
+  // extreme scale factors (more source rows per tile than the LDS stage holds): one pass, straight from global
+  for (int q = tid; q < qw * nrows; q += 256) {
+    const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
+    const int2 yt = sY[ry];
+    const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
+    const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+    const uint8_t *S0 = src + mul24((uint32_t)sy0, (uint32_t)spitch), *S1 = src + mul24((uint32_t)sy1, (uint32_t)spitch);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int2 xt = sX[dx0 + j];            // columns past the row end repeat the last one (padded table); only [0, w) is stored
+      const int sx = xt.x, sx1 = min(sx + 1, Gs.w - 1);
+      const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+      const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+      const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+      const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      packed |= (uint32_t)v << (8 * j);
+    }
+    uint8_t *dst = dstplane + mul24((uint32_t)dy, (uint32_t)G.pitch);
+    if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
+    else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -639,8 +639,10 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   for (int l = 1; l < h->nlevels; l++) {
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
-    const size_t lds = align_up((size_t)((G.w + 3) & ~3) * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes;   // x table padded to whole quads
-    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes);
+    const int wq = (G.w + 3) & ~3;                                       // x table and T rows padded to whole quads
+    const int tPitch = (int)align_up((size_t)wq * 2, 8);                 // horizontally interpolated rows, 16 bits per column
+    const size_t lds = align_up((size_t)wq * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes + (size_t)RESIZE_MAXSRC * tPitch;
+    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
