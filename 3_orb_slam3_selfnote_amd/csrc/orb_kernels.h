@@ -149,15 +149,19 @@ __device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: cv::resize INTER_LINEAR 8UC1.  Level `level` of every frame from level-1.
-// Thread = 4 consecutive output pixels (one 32-bit store); block = 64x4 threads = 256x4 output pixels.
-// Tables {sx, a0|a1<<16} / {sy, b0|b1<<16} are built on the host (orbx_configure).
+// Tables {sx, a0|a1<<16} / {sy, b0|b1<<16} are built on the host (orbx_configure); the result is
+//   (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2,   r = S[sy][sx] * a0 + S[sy][sx + 1] * a1   for rows sy, sy + 1.
+// Workgroup = RESIZE_ROWS output rows x full width.
+//
+// Two-pass form (tPitch > 0, the host's choice whenever a tile's source rows fit the LDS stage): the horizontal interpolation r >> 4
+// of a source row is shared by the two output rows that straddle it, so it is evaluated once per (source row, output column) -
+// about 1.4 per output pixel for 8-row tiles at scale 1.2 instead of 2 - into a 16-bit LDS plane T, and the vertical pass reads
+// four finished values with one 8-byte LDS load (SQ_INSTS_VALU per launch 13.3 M -> 9.8 M against the one-pass gather form).
+// One-pass form (tPitch == 0): extreme scale factors, straight from global memory.
 // ------------------------------------------------------------------------------------------------------------
-// One level of every frame.  Workgroup = RESIZE_ROWS output rows x full width: the <= 1.2*RESIZE_ROWS+2 source rows
-// it needs are staged in LDS with coalesced dword loads (plus the x coefficient table), so the 16 byte gathers per
-// output quad hit LDS instead of issuing 16 global byte loads (the first version was load-issue bound).
 #define RESIZE_ROWS 8
-#define RESIZE_MAXSRC 16   // source rows per tile: floor(1.2*(RESIZE_ROWS-1)) + 2 with margin (scale <= 1.6 supported)
-__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes, int tPitch) {
+#define RESIZE_MAXSRC 16   // most source rows per tile the two-pass form stages: floor(1.2*(RESIZE_ROWS-1)) + 2 with margin (scale <= 1.6)
+__global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes, int tPitch, int maxSrc) {
   extern __shared__ __align__(16) uint8_t smem_rs[];
   const LevelGeom G = P.geom[level];
   const LevelGeom Gs = P.geom[level - 1];
@@ -168,24 +172,29 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
   const int nrows = min(RESIZE_ROWS, G.h - dy0);
   int spitch;
   const uint8_t *src = level_plane(P, frame, level - 1, spitch);
-  // source row span of this tile
-  const int syFirst = min(max(P.ytab[G.ytabBase + dy0].x, 0), Gs.h - 1);
-  const int syLast = min(max(P.ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), Gs.h - 1);
-  const int nsrc = syLast - syFirst + 1;
-  int2 *sX = reinterpret_cast<int2 *>(smem_rs);                       // [G.w]
-  // the x table is padded to whole output quads with copies of its last entry: the row loop then needs no column clamp
-  const int wq = (G.w + 3) & ~3;
-  const size_t sRowsOff = ((size_t)wq * 8 + 15) & ~(size_t)15;
-  uint8_t *sRows = smem_rs + sRowsOff;   // [nsrc][smemRowBytes]
-  for (int i = tid; i < wq; i += 256) sX[i] = P.xtab[G.xtabBase + min(i, G.w - 1)];
-  // the tile's y-coefficients go through LDS as well: the row loop below then has no global load in front of its gathers
+  uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
+  const int wq = (G.w + 3) & ~3, qw = wq >> 2;   // the x table is padded to whole output quads with copies of its last entry (host)
+  // the tile's y-coefficients go through LDS: the row code below then has no global load in front of it
   __shared__ int2 sY[RESIZE_ROWS];
   if (tid < nrows) sY[tid] = P.ytab[G.ytabBase + dy0 + tid];
-  const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
-  // Index arithmetic: 32-bit integer multiplies issue at a quarter of the full rate, so idx / ndw is taken in float --
-  // (idx + 0.5) / ndw stays at least 0.5 / ndw >= 2^-11 away from an integer while the rounding error of the product is
-  // below 2^-19 for idx < 2^14, so truncation yields the exact quotient -- and offsets use 24-bit multiplies (mul24).
-  if (nsrc <= RESIZE_MAXSRC) {
+
+  if (tPitch > 0) {
+    // source row span of this tile (at most maxSrc rows: the host derived maxSrc from the same table)
+    const int syFirst = min(max(P.ytab[G.ytabBase + dy0].x, 0), Gs.h - 1);
+    const int syLast = min(max(P.ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), Gs.h - 1);
+    const int nsrc = min(syLast - syFirst + 1, maxSrc);
+    uint8_t *sRows = smem_rs;                                  // [maxSrc][smemRowBytes]
+    uint8_t *sT = sRows + (size_t)maxSrc * smemRowBytes;       // [maxSrc][tPitch] bytes, u16 entries
+    uint4 *sRowRec = reinterpret_cast<uint4 *>(sT + (size_t)maxSrc * tPitch);   // [RESIZE_ROWS]
+    // this thread's first two column pairs of pass 1, loaded ahead of the staging (a level up to 1024 columns wide needs no more)
+    const int4 *xtab4 = reinterpret_cast<const int4 *>(P.xtab + G.xtabBase);
+    int4 xtPre[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const int p = tid + 256 * k; xtPre[k] = 2 * p < wq ? xtab4[p] : make_int4(0, 0, 0, 0); }
+    const bool aligned = ((((uintptr_t)src) | (uintptr_t)spitch) & 3u) == 0;
+    // Index arithmetic: 32-bit integer multiplies issue at a quarter of the full rate, so idx / ndw is taken in float --
+    // (idx + 0.5) / ndw stays at least 0.5 / ndw >= 2^-11 away from an integer while the rounding error of the product is
+    // below 2^-19 for idx < 2^14, so truncation yields the exact quotient -- and offsets use 24-bit multiplies (mul24).
     const uint8_t *src0 = src + (size_t)syFirst * spitch;
     if (aligned) {
       // Full 16-byte chunks of every source row by LDS-DMA (global_load_lds_dwordx4: no register, no ds_write).  The LDS rows
@@ -221,59 +230,91 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
         sRows[mul24((uint32_t)r, (uint32_t)smemRowBytes) + c] = src0[mul24((uint32_t)r, (uint32_t)spitch) + c];
       }
     }
-  }
-  __syncthreads();
-  uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
-  const int qw = (G.w + 3) >> 2;
-  // q / qw in float: (q + 0.5) / qw is at least 0.5 / qw >= 2^-11 away from an integer, the product's rounding error is
-  // below 2^-19 for q < 8 * 1024, so truncation gives the exact quotient (four full-rate operations)
-  const float inv_qw = 1.0f / (float)qw;
-  if (nsrc <= RESIZE_MAXSRC) {
-    // Two passes, because the horizontal interpolation of a source row is shared by the two output rows that straddle it: the one-pass
-    // form evaluates it twice per output pixel, here it is evaluated once per (source row, output column) - about 1.4 per output pixel
-    // for 8-row tiles at scale 1.2 - and the vertical pass reads four finished values with one 8-byte LDS load.
-    // Pass 1: T[r][c] = (S[r][sx] * a0 + S[r][sx + 1] * a1) >> 4, at most 255 * 2048 / 16 = 32640: 16 bits.  Thread = output column,
-    // loop over the staged source rows: the column's table entry is read once.  Column sx + 1 = w exists in the LDS rows (they are
-    // padded to 16-byte chunks) and is only ever read with weight a1 = 0 (the table clamps sx to w - 1 with fx = 0 there).
-    uint8_t *sT = sRows + (size_t)RESIZE_MAXSRC * smemRowBytes;     // [nsrc][tPitch] bytes, u16 entries
-    for (int c = tid; c < wq; c += 256) {
-      const int2 xt = sX[c];
-      const uint32_t a0 = (uint32_t)xt.y & 0xffffu, a1 = (uint32_t)xt.y >> 16;
-      const uint8_t *sp = sRows + xt.x;
-      uint8_t *tp = sT + 2 * c;
-#pragma unroll 4
-      for (int r = 0; r < nsrc; r++) {
-        const uint32_t v = mul24_vv((uint32_t)sp[0], a0) + mul24_vv((uint32_t)sp[1], a1);
-        *reinterpret_cast<uint16_t *>(tp) = (uint16_t)(v >> 4);
-        sp += smemRowBytes;
-        tp += tPitch;
+    // per output row of the tile: where its two T rows start, its coefficient pair, where it goes
+    if (tid < nrows) {
+      const int2 yt = P.ytab[G.ytabBase + dy0 + tid];
+      const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
+      sRowRec[tid] = make_uint4((uint32_t)((sy0 - syFirst) * tPitch), (uint32_t)((sy1 - syFirst) * tPitch), (uint32_t)yt.y, (uint32_t)((dy0 + tid) * G.pitch));
+    }
+    __syncthreads();
+    // Pass 1: T[r][c] = (S[r][sx] * a0 + S[r][sx + 1] * a1) >> 4, at most 255 * 2048 / 16 = 32640: 16 bits.  Thread = two neighbouring
+    // output columns, loop over the staged source rows.  Per row ONE aligned 8-byte window [base, base + 8), base = sx_A & ~3, holds all
+    // four source bytes (sx_B - sx_A <= 3: the host takes this form for horizontal scale factors below 3 only): v_perm_b32 picks each
+    // column's byte pair out of it as two 16-bit halves, v_dot2_u32_u16 multiplies by the column's coefficient pair - pre-scaled by 16
+    // (a << 4 <= 2^15 still fits its half), which moves the >> 4 to a byte boundary: the product's bytes 1..2 are T - and a third
+    // v_perm_b32 packs the two T values into one 32-bit store: five vector instructions per row for two columns, and no byte access
+    // that straddles a dword (the straightforward byte-pair read compiles to an unaligned ds_read_u16, which the LDS serialises:
+    // measured 25 cycles per LDS instruction, 3x the whole kernel's time).
+    // Column sx + 1 = w exists in the LDS rows (they are padded to 16-byte chunks) and is only ever read with weight a1 = 0 (the table
+    // clamps sx to w - 1 with fx = 0 there); the window's other bytes may be anything, they are never selected.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](uint32_t pix, uint32_t coef) -> uint32_t {
+      u16x2 x, y;
+      __builtin_memcpy(&x, &pix, 4); __builtin_memcpy(&y, &coef, 4);
+      return __builtin_amdgcn_udot2(x, y, 0u, false);
+    };
+    int trip = 0;
+    for (int p = tid; 2 * p < wq; p += 256, trip++) {
+      const int4 xt = trip == 0 ? xtPre[0] : trip == 1 ? xtPre[1] : xtab4[p];     // {sx_A, coef_A, sx_B, coef_B}
+      const uint32_t base = (uint32_t)xt.x & ~3u, oA = (uint32_t)xt.x & 3u, oB = (uint32_t)xt.z - base;
+      const uint32_t selA = 0x0c000c00u | oA | ((oA + 1u) << 16), selB = 0x0c000c00u | oB | ((oB + 1u) << 16);
+      const uint32_t kA = (uint32_t)xt.y << 4, kB = (uint32_t)xt.w << 4;
+      const uint8_t *sp = sRows + base;
+      uint8_t *tp = sT + 4 * p;
+      // four rows per trip, all loads first: the compiler may not move an LDS load over an LDS store (T and the staged rows could alias
+      // for all it knows), and one load -> store chain per row is one LDS latency per row
+      for (int r = 0; r < nsrc; r += 4) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(sp + min(r + k, nsrc - 1) * smemRowBytes);       // uniform: scalar arithmetic
+          lo[k] = q[0]; hi[k] = q[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (r + k < nsrc) {
+            const uint32_t vA = dot2(__builtin_amdgcn_perm(hi[k], lo[k], selA), kA), vB = dot2(__builtin_amdgcn_perm(hi[k], lo[k], selB), kB);
+            *reinterpret_cast<uint32_t *>(tp + (r + k) * tPitch) = __builtin_amdgcn_perm(vB, vA, 0x06050201u);
+          }
       }
     }
     __syncthreads();
-    // Pass 2: thread = 4 consecutive output pixels of one row.  No saturate_cast needed: the coefficients are non-negative and each
-    // pair sums to 2048, so v is a convex combination of four bytes, rounded down-ish: always inside [0, 255].
-    for (int q = tid; q < qw * nrows; q += 256) {
-      const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
-      const int2 yt = sY[ry];
-      const int sy0 = min(max(yt.x, 0), Gs.h - 1), sy1 = min(max(yt.x + 1, 0), Gs.h - 1);
-      const uint32_t b0 = (uint32_t)yt.y & 0xffffu, b1 = (uint32_t)yt.y >> 16;
-      const uint2 t0 = *reinterpret_cast<const uint2 *>(sT + mul24((uint32_t)(sy0 - syFirst), (uint32_t)tPitch) + 8 * (dx0 >> 2));
-      const uint2 t1 = *reinterpret_cast<const uint2 *>(sT + mul24((uint32_t)(sy1 - syFirst), (uint32_t)tPitch) + 8 * (dx0 >> 2));
-      const uint32_t u0[4] = {t0.x & 0xffffu, t0.x >> 16, t0.y & 0xffffu, t0.y >> 16};
-      const uint32_t u1[4] = {t1.x & 0xffffu, t1.x >> 16, t1.y & 0xffffu, t1.y >> 16};
-      uint32_t packed = 0;
+    // Pass 2: 32 threads per output row (RESIZE_ROWS x 32 = the workgroup), each 4 consecutive output pixels per trip: everything that
+    // depends on the row alone is read once, a trip is two 8-byte LDS loads, the arithmetic and one 32-bit store.  No saturate_cast
+    // needed: the coefficients are non-negative and each pair sums to 2048, so v is a convex combination of four bytes, rounded
+    // down-ish: always inside [0, 255].
+    static_assert(RESIZE_ROWS * 32 == 256, "pass 2 maps 32 threads to each output row of the tile");
+    const int ry = tid >> 5;
+    if (ry < nrows) {
+      const uint4 rec = sRowRec[ry];
+      const uint32_t b0 = rec.z & 0xffffu, b1 = rec.z >> 16;
+      const uint8_t *T0 = sT + rec.x, *T1 = sT + rec.y;
+      uint8_t *dst = dstplane + rec.w;
+      for (int qx = tid & 31; qx < qw; qx += 32) {
+        const uint2 t0 = *reinterpret_cast<const uint2 *>(T0 + 8 * qx), t1 = *reinterpret_cast<const uint2 *>(T1 + 8 * qx);
+        const uint32_t u0[4] = {t0.x & 0xffffu, t0.x >> 16, t0.y & 0xffffu, t0.y >> 16};
+        const uint32_t u1[4] = {t1.x & 0xffffu, t1.x >> 16, t1.y & 0xffffu, t1.y >> 16};
+        uint32_t packed = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t v = ((mul24_vv(b0, u0[j]) >> 16) + (mul24_vv(b1, u1[j]) >> 16) + 2) >> 2;
-        packed |= v << (8 * j);
+        for (int j = 0; j < 4; j++) {
+          const uint32_t v = ((mul24_vv(b0, u0[j]) >> 16) + (mul24_vv(b1, u1[j]) >> 16) + 2) >> 2;
+          packed |= v << (8 * j);
+        }
+        const int dx0 = 4 * qx;
+        if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
+        else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
       }
-      uint8_t *dst = dstplane + mul24((uint32_t)dy, (uint32_t)G.pitch);
-      if (dx0 + 3 < G.w) *reinterpret_cast<uint32_t *>(dst + dx0) = packed;
-      else for (int j = 0; j < 4 && dx0 + j < G.w; j++) dst[dx0 + j] = (uint8_t)(packed >> (8 * j));
     }
     return;
   }
-  // extreme scale factors (more source rows per tile than the LDS stage holds): one pass, straight from global
+
+  // One-pass form: the x table in LDS, the four source bytes of every output pixel straight from global memory.
+  int2 *sX = reinterpret_cast<int2 *>(smem_rs);                       // [wq]
+  for (int i = tid; i < wq; i += 256) sX[i] = P.xtab[G.xtabBase + i];
+  __syncthreads();
+  // q / qw in float: (q + 0.5) / qw is at least 0.5 / qw >= 2^-11 away from an integer, the product's rounding error is
+  // below 2^-19 for q < 8 * 1024, so truncation gives the exact quotient (four full-rate operations)
+  const float inv_qw = 1.0f / (float)qw;
   for (int q = tid; q < qw * nrows; q += 256) {
     const int ry = (int)(((float)q + 0.5f) * inv_qw), dx0 = (q - (int)mul24((uint32_t)ry, (uint32_t)qw)) * 4, dy = dy0 + ry;
     const int2 yt = sY[ry];

@@ -398,6 +398,9 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         int a1 = std::min(std::max(cv_round(fx * 2048), -32768), 32767);
         xtab.push_back(make_int2(sx, (a0 & 0xffff) | (a1 << 16)));
       }
+      // k_resize reads the table two columns at a time with 16-byte loads and computes whole output quads: a level's entries start at
+      // an even index (xtabBase, below) and are followed by copies of the last one up to a multiple of four columns
+      while ((xtab.size() - (size_t)G.xtabBase) % 4) xtab.push_back(xtab.back());
       for (int dy = 0; dy < G.h; dy++) {
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
         int sy = (int)floor(fy);
@@ -405,6 +408,12 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         int b0 = std::min(std::max(cv_round((1.f - fy) * 2048), -32768), 32767);
         int b1 = std::min(std::max(cv_round(fy * 2048), -32768), 32767);
         ytab.push_back(make_int2(sy, (b0 & 0xffff) | (b1 << 16)));
+      }
+      G.resizeSrcRows = 0;
+      for (int dy0 = 0; dy0 < G.h; dy0 += RESIZE_ROWS) {   // as k_resize derives a tile's source rows
+        const int nrows = std::min(RESIZE_ROWS, G.h - dy0);
+        const int f = std::min(std::max(ytab[G.ytabBase + dy0].x, 0), sh - 1), la = std::min(std::max(ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), sh - 1);
+        G.resizeSrcRows = std::max(G.resizeSrcRows, la - f + 1);
       }
     }
   }
@@ -639,10 +648,14 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   for (int l = 1; l < h->nlevels; l++) {
     const LevelGeom &G = h->geom[l], &Gs = h->geom[l - 1];
     const int rowBytes = (int)align_up((size_t)Gs.w + 4, 16);
-    const int wq = (G.w + 3) & ~3;                                       // x table and T rows padded to whole quads
-    const int tPitch = (int)align_up((size_t)wq * 2, 8);                 // horizontally interpolated rows, 16 bits per column
-    const size_t lds = align_up((size_t)wq * 8, 16) + (size_t)RESIZE_MAXSRC * rowBytes + (size_t)RESIZE_MAXSRC * tPitch;
-    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch);
+    // Two-pass form (rows and their horizontal interpolation staged in LDS) whenever a tile's source rows fit the stage and pass 1's
+    // precondition holds (two neighbouring columns' source bytes inside one aligned 8-byte window: horizontal scale factor below 3);
+    // otherwise the one-pass form straight from global memory (tPitch 0), which stages the x table only.
+    const int wq = (G.w + 3) & ~3;
+    const bool twoPass = G.resizeSrcRows <= RESIZE_MAXSRC && (double)Gs.w / G.w < 3.0;
+    const int tPitch = twoPass ? (int)align_up((size_t)wq * 2, 8) : 0;     // horizontally interpolated rows, 16 bits per column
+    const size_t lds = twoPass ? (size_t)G.resizeSrcRows * (rowBytes + tPitch) + 16 * RESIZE_ROWS : (size_t)wq * 8;
+    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch, G.resizeSrcRows);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);

@@ -273,6 +273,8 @@ def test_full_size_properties(pkg, frame):
     dict(H=130, W=150, nfeatures=500, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),      # upper levels smaller than one cell
     dict(H=1080, W=1920, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7),   # full HD: long rows in every staging loop
     dict(H=613, W=1021, nfeatures=1200, scaleFactor=1.3, nlevels=6, iniThFAST=15, minThFAST=5),    # odd sizes: unaligned level-0 rows, ragged row tails
+    dict(H=500, W=700, nfeatures=300, scaleFactor=2.6, nlevels=3, iniThFAST=20, minThFAST=7),      # k_resize's one-pass form: a tile's source rows exceed its LDS stage
+    dict(H=600, W=900, nfeatures=200, scaleFactor=3.3, nlevels=2, iniThFAST=20, minThFAST=7),      # ... and neighbouring columns more than 3 source bytes apart
 ])
 def test_extract_parity_config_matrix(pkg, oracle, synth, cfg):
     """Geometry / parameter sweep: other datasets' image sizes, scale factors, level counts, thresholds, quotas."""
