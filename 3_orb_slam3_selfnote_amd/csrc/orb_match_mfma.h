@@ -228,3 +228,134 @@ __global__ __launch_bounds__(MF_NT) void k_match_scan_mfma(MatchProblemSet M, ui
     o[1] = make_uint4(out[4], out[5], out[6], out[7]);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// The same product behind the two brute-force entries (orbm_hamming_matrix, orbm_knn_match2): one operand streams through LDS in
+// 32-descriptor tiles (A, rows), the other stays in registers (B, a wavefront's 64 columns), 16 MFMAs per tile and wavefront.
+// ------------------------------------------------------------------------------------------------------------
+// B fragments of one descriptor (column `col` of a 32-column tile), this lane's half h of every K-step
+__device__ __forceinline__ void mf_b_frags(const uint32_t *desc8, int h, mf_v4i B[8]) {
+  const uint4 a = reinterpret_cast<const uint4 *>(desc8)[0], b = reinterpret_cast<const uint4 *>(desc8)[1];
+  const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int s = 0; s < 8; s++) B[s] = mf_expand16((d[s] >> (16 * h)) & 0xffffu, MF_LUT_QUERY);
+}
+// A tile: rows [base, base + 32) of `desc` (n rows of 8 words; rows past n are zero descriptors) expanded into sA (8 KiB, chunk c of
+// row r at position r * 16 + ((c + r) & 15)); all MF_NT threads, two (row, chunk) items each
+__device__ __forceinline__ void mf_stage_rows(const uint32_t *desc, int n, int base, uint8_t *sA) {
+  const int tid = threadIdx.x, it_r = tid >> 4, it_c = tid & 15;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int r = it_r + 16 * k;
+    const uint32_t raw = base + r < n ? desc[(size_t)(base + r) * 8 + (it_c >> 1)] : 0u;
+    *reinterpret_cast<mf_v4i *>(&sA[(r * 16 + ((it_c + r) & 15)) * 16]) = mf_expand16((raw >> (16 * (it_c & 1))) & 0xffffu, MF_LUT_CAND);
+  }
+}
+__device__ __forceinline__ void mf_tile_product(const uint8_t *sA, int col, int h, const mf_v4i B0[8], const mf_v4i B1[8], mf_v16i &acc0, mf_v16i &acc1) {
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const mf_v4i a = *reinterpret_cast<const mf_v4i *>(&sA[(col * 16 + ((2 * s + h + col) & 15)) * 16]);
+    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[s], acc1, 0, 0, 0);
+  }
+}
+
+// K8 brute force on the matrix pipe: dist[i][j] = popcount(q_i ^ c_j).  Rows = queries (streamed), columns = candidates (a workgroup's
+// 256, resident): a store instruction then writes two runs of 32 consecutive candidates of two query rows.  The accumulator starts at
+// 2^18, so D = 2048 * ham.  Grid: (ceil(nc / 256), query slabs of qslab rows).
+__global__ __launch_bounds__(MF_NT) void k_hamming_matrix_mfma(const uint32_t *q, int nq, const uint32_t *c, int nc, uint16_t *dist, int qslab) {
+  __shared__ __align__(16) uint8_t sA[2][MF_TILE * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.x * MF_NT + wid * 64 + col, c1 = c0 + 32;
+  mf_v4i B0[8], B1[8];
+  mf_b_frags(c + (size_t)min(c0, nc - 1) * 8, h, B0);
+  mf_b_frags(c + (size_t)min(c1, nc - 1) * 8, h, B1);
+  const int qBeg = blockIdx.y * qslab, qEnd = min(qBeg + qslab, nq);
+  const int ntiles = (qEnd - qBeg + MF_TILE - 1) / MF_TILE;
+  if (ntiles > 0) mf_stage_rows(q, qEnd, qBeg, sA[0]);
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    const int buf = t & 1, base = qBeg + t * MF_TILE;
+    if (t + 1 < ntiles) mf_stage_rows(q, qEnd, base + MF_TILE, sA[buf ^ 1]);
+    mf_v16i acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = (int)MF_REC_BASE; acc1[r] = (int)MF_REC_BASE; }
+    mf_tile_product(sA[buf], col, h, B0, B1, acc0, acc1);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = base + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < qEnd) {
+        uint16_t *o = dist + (size_t)row * nc;
+        if (c0 < nc) o[c0] = (uint16_t)((uint32_t)acc0[r] >> 11);
+        if (c1 < nc) o[c1] = (uint16_t)((uint32_t)acc1[r] >> 11);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// knnMatch(k = 2) on the matrix pipe: columns = queries (a lane owns one), rows = train descriptors streamed in super-blocks of 2048:
+// inside a super-block the accumulator seed 2^18 + (row index in the block) makes D = ham << 11 | index, a ready (distance, train
+// index) key for the per-lane sorted pair (MfList<2>: one v_min and one v_med3 per key); at the end of a super-block the pair is
+// rewritten with the global train index (ham << 20 | index, nc < 2^20) and merged into the running pair.
+__global__ __launch_bounds__(MF_NT) void k_knn2_mfma(const uint32_t *q, int nq, const uint32_t *c, int nc, int32_t *idx2, int32_t *dist2) {
+  __shared__ __align__(16) uint8_t sA[2][MF_TILE * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * MF_NT + wid * 64 + col, q1 = q0 + 32;
+  mf_v4i B0[8], B1[8];
+  mf_b_frags(q + (size_t)min(q0, nq - 1) * 8, h, B0);
+  mf_b_frags(q + (size_t)min(q1, nq - 1) * 8, h, B1);
+  uint32_t g0[2] = {0xffffffffu, 0xffffffffu}, g1[2] = {0xffffffffu, 0xffffffffu};   // running pairs, global keys
+  auto fold = [](uint32_t g[2], const MfList<2> &L, int sb) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t k = L.top[j];
+      const uint32_t key = k < MF_KEY_LIMIT ? ((k >> 11) << 20) | (uint32_t)(sb + (int)(k & 0x7ffu)) : 0xffffffffu;
+      g[1] = mf_med3(g[0], g[1], key);
+      g[0] = min(g[0], key);
+    }
+  };
+  for (int sb = 0; sb < nc; sb += 2048) {
+    const int sbEnd = min(sb + 2048, nc), ntiles = (sbEnd - sb + MF_TILE - 1) / MF_TILE;
+    MfList<2> L0, L1;
+    L0.init(); L1.init();
+    __syncthreads();                       // the previous super-block's last tile is no longer read
+    mf_stage_rows(c, sbEnd, sb, sA[0]);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+      const int buf = t & 1, base = sb + t * MF_TILE;
+      if (t + 1 < ntiles) mf_stage_rows(c, sbEnd, base + MF_TILE, sA[buf ^ 1]);
+      mf_v16i acc0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = t * MF_TILE + (r & 3) + 8 * (r >> 2) + 4 * h;      // index inside the super-block
+        acc0[r] = (int)(sb + row < sbEnd ? MF_REC_BASE + (uint32_t)row : MF_REC_UNUSABLE);
+      }
+      mf_v16i acc1 = acc0;
+      mf_tile_product(sA[buf], col, h, B0, B1, acc0, acc1);
+      L0.take(acc0);
+      L1.take(acc1);
+      __syncthreads();
+    }
+    fold(g0, L0, sb);
+    fold(g1, L1, sb);
+  }
+  // the two lanes of a column saw the two halves of every tile: lane h reports tile h's query and merges the partner's pair for it
+  uint32_t mine[2], other[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    mine[j] = h ? g1[j] : g0[j];
+    other[j] = (uint32_t)__shfl_xor((int)(h ? g0[j] : g1[j]), 32, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) { mine[1] = mf_med3(mine[0], mine[1], other[j]); mine[0] = min(mine[0], other[j]); }
+  const int qi = h ? q1 : q0;
+  if (qi < nq) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const bool real = mine[j] != 0xffffffffu;
+      idx2[2 * qi + j] = real ? (int32_t)(mine[j] & 0xfffffu) : -1;
+      dist2[2 * qi + j] = real ? (int32_t)(mine[j] >> 20) : -1;
+    }
+  }
+}

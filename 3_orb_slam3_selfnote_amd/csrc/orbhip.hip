@@ -2637,7 +2637,11 @@ int orbm_knn_match2(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, int n
   MCHECK(m, hipMemcpyAsync(m->d_a.p, q, 32 * (size_t)nq, hipMemcpyHostToDevice, s));
   MCHECK(m, hipMemcpyAsync(m->d_b.p, c, 32 * (size_t)nc, hipMemcpyHostToDevice, s));
   int32_t *d_idx = (int32_t *)m->d_c.p, *d_dist = d_idx + 2 * (size_t)nq;
-  hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc, d_idx, d_dist);
+  // matrix-pipe form (orb_match_mfma.h) unless the vector-ALU engine is selected; its keys carry the train index in 20 bits
+  if (m->hamming_engine >= 1 && nc < (1 << 20))
+    hipLaunchKernelGGL(k_knn2_mfma, dim3((nq + MF_NT - 1) / MF_NT), dim3(MF_NT), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc, d_idx, d_dist);
+  else
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc, d_idx, d_dist);
   MCHECK(m, hipGetLastError());
   MCHECK(m, hipMemcpyAsync(idx2, d_idx, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
   MCHECK(m, hipMemcpyAsync(dist2, d_dist, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, s));
@@ -2654,8 +2658,13 @@ int orbm_hamming_matrix(orbm_t *m, const uint8_t *q, int nq, const uint8_t *c, i
   MCHECK(m, m->d_c.reserve(sizeof(uint16_t) * (size_t)nq * nc));
   MCHECK(m, hipMemcpyAsync(m->d_a.p, q, 32 * (size_t)nq, hipMemcpyHostToDevice, s));
   MCHECK(m, hipMemcpyAsync(m->d_b.p, c, 32 * (size_t)nc, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_hamming_matrix, dim3((nq + 255) / 256), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc,
-                     (uint16_t *)m->d_c.p);
+  constexpr int QSLAB = 128;   // query rows per workgroup of the matrix-pipe form: four tiles behind one expansion of its 256 candidates
+  if (m->hamming_engine >= 1 && (nq + QSLAB - 1) / QSLAB <= 65535)
+    hipLaunchKernelGGL(k_hamming_matrix_mfma, dim3((nc + MF_NT - 1) / MF_NT, (nq + QSLAB - 1) / QSLAB), dim3(MF_NT), 0, s, (const uint32_t *)m->d_a.p, nq,
+                       (const uint32_t *)m->d_b.p, nc, (uint16_t *)m->d_c.p, QSLAB);
+  else
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nq + 255) / 256), dim3(256), 0, s, (const uint32_t *)m->d_a.p, nq, (const uint32_t *)m->d_b.p, nc,
+                       (uint16_t *)m->d_c.p);
   MCHECK(m, hipGetLastError());
   MCHECK(m, hipMemcpyAsync(dist, m->d_c.p, sizeof(uint16_t) * (size_t)nq * nc, hipMemcpyDeviceToHost, s));
   MCHECK(m, hipStreamSynchronize(s));

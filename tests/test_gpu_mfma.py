@@ -213,3 +213,47 @@ def test_in_view_queries_whose_window_is_outside_the_grid(pkg, oracle, stream):
     for th in (255, 100):
         ref = check(pkg, oracle, cand, qry, bounds, sf, nnratio=0.6, th=th, second=False)
         assert all((r[1][np.arange(7, len(r[1]), 53)] == -1).all() for r in ref)
+
+
+def _dist_matrix(q, c):
+    return np.unpackbits(q[:, None, :] ^ c[None, :, :], axis=2).sum(axis=2).astype(np.int64)
+
+
+@pytest.mark.parametrize("nq,nc", [(1000, 1000), (7, 301), (129, 257), (1, 1), (300, 2500)])
+def test_hamming_matrix_both_engines(pkg, synth, nq, nc):
+    """orbm_hamming_matrix on the matrix pipe (engines 1 / 2: k_hamming_matrix_mfma) and on the vector ALU (engine 0) against numpy:
+    query slabs and candidate blocks with ragged tails, a single pair, more than one 256-candidate block."""
+    n = max(nq, nc)
+    q, c = synth.make_descriptor_sets(2100 + n, n=n)
+    q, c = q[:nq], c[:nc]
+    ref = _dist_matrix(q, c).astype(np.uint16)
+    for engine in (2, 0):
+        m = pkg.ORBmatcher(0.8, True)
+        m.set_hamming_engine(engine)
+        assert np.array_equal(m.hamming_matrix(q, c), ref), engine
+        m.close()
+
+
+@pytest.mark.parametrize("nq,nc", [(700, 705), (260, 33), (3, 1), (65, 2049), (40, 4500)])
+def test_knn_match2_both_engines(pkg, synth, nq, nc):
+    """knnMatch(k = 2) (Frame.cc:1246) on the matrix pipe (k_knn2_mfma: sorted pair per lane, 2048-descriptor super-blocks) and on the
+    vector ALU: duplicated train descriptors (tied distances, ordered by train index) across tile, half-tile and super-block borders."""
+    n = max(nq, nc)
+    q, c = synth.make_descriptor_sets(5500 + n, n=n)
+    q, c = q[:nq].copy(), c[:nc].copy()
+    if nc > 40:
+        c[-5:] = c[:5]                      # the same descriptor at both ends of the train set
+        c[33] = c[31]; c[16] = c[15]        # across a tile border, across the two halves of a tile
+        q[0] = c[15]                        # distance 0 twice
+    D = _dist_matrix(q, c)
+    order = np.argsort(D * (1 << 20) + np.arange(nc)[None, :], axis=1)[:, :2]
+    for engine in (2, 0):
+        m = pkg.ORBmatcher(0.8, True)
+        m.set_hamming_engine(engine)
+        idx, dist = m.knnMatch2(q, c)
+        if nc >= 2:
+            assert np.array_equal(idx, order.astype(np.int32)), engine
+            assert np.array_equal(dist, np.take_along_axis(D, order, axis=1).astype(np.int32)), engine
+        else:
+            assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all() and (dist[:, 1] == -1).all() and np.array_equal(dist[:, 0], D[:, 0]), engine
+        m.close()
