@@ -680,6 +680,9 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 #endif
 struct OctNode { short ulx, urx, uly, bry; };
 
+#ifndef OCT_REGKEYS
+#define OCT_REGKEYS 4096   // keys of a level held in registers (the rest goes through the global cand / knode arrays)
+#endif
 template <int NT, bool CELLS_LDS>
 __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffScratch) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -712,6 +715,29 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   int32_t *lcnt = P.lcnt + ((size_t)frame * P.nlevels + level) * 2;
   uint32_t *cand = P.cand + (size_t)frame * P.cand_fs + G.candBase;
   uint16_t *knode = P.knode + (size_t)frame * P.cand_fs + G.candBase;
+  // The keys never move and every pass over them uses the same thread <-> key assignment (k = tid + j * NT), so the first 4096 keys
+  // of a level - all of them on any frame seen so far (EuRoC: 600 .. 3300 per level) - live in REGISTERS: the packed candidate and its
+  // node label, PER of each per thread.  The rounds then touch no memory but the node tables in LDS; the global cand / knode arrays
+  // only serve keys beyond 4096 (round 2 re-read and re-wrote both arrays every round: 4.8x the kernel's algorithmic traffic, and a
+  // global round trip in front of both key passes of every round).
+  constexpr int PER = OCT_REGKEYS / NT, REGN = PER * NT;
+  uint32_t rc[PER > 0 ? PER : 1], rk[PER > 0 ? PER : 1];
+#pragma unroll
+  for (int j = 0; j < PER; j++) { rc[j] = 0u; rk[j] = 0u; }
+  // f(k, c, nd): k dense key index, c packed candidate, nd node label (both by reference)
+  auto for_keys = [&](int n_, auto f) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      if (j * NT >= n_) break;
+      const int k = tid + j * NT;
+      if (k < n_) f(k, rc[j], rk[j]);
+    }
+    for (int k = REGN + tid; k < n_; k += NT) {
+      uint32_t c = cand[k], nd = knode[k];
+      f(k, c, nd);
+      knode[k] = (uint16_t)nd;
+    }
+  };
 
   // ---- A. compact the per-cell slot lists into vToDistributeKeys order (cells row-major, raster inside) ----
   // Cell offsets by a workgroup scan (kept in LDS when they fit: CELLS_LDS), then one thread per candidate finds its
@@ -746,23 +772,37 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   {
     const uint32_t *slots = P.slots + (size_t)frame * P.slot_fs + G.slotBase;
     if (CELLS_LDS) {
-      for (int k = tid; k < n; k += NT) {
+      auto fetch = [&](int k) -> uint32_t {
         int lo = 0, hi = ncell - 1;                  // last cell whose offset is <= k (empty cells share offsets)
         while (lo < hi) {
           const int mid = (lo + hi + 1) >> 1;
           if (cellOffL[mid] <= (uint32_t)k) lo = mid; else hi = mid - 1;
         }
-        cand[k] = slots[(size_t)lo * G.cellCap + ((uint32_t)k - cellOffL[lo])];
+        return slots[(size_t)lo * G.cellCap + ((uint32_t)k - cellOffL[lo])];
+      };
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        if (j * NT >= n) break;
+        const int k = tid + j * NT;
+        if (k < n) { rc[j] = fetch(k); cand[k] = rc[j]; }   // the global copy is written once and never read back (orbx_debug_candidates, stage parity tests)
       }
+      for (int k = REGN + tid; k < n; k += NT) cand[k] = fetch(k);
+      __syncthreads();
     } else {
       for (int cidx = wid; cidx < ncell; cidx += NW) {
         uint32_t cnt = cellCnt[cidx], off = cellOffG[cidx];
         for (uint32_t j = lane; j < cnt; j += 64)
           if (off + j < (uint32_t)n) cand[off + j] = slots[(size_t)cidx * G.cellCap + j];
       }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        if (j * NT >= n) break;
+        const int k = tid + j * NT;
+        if (k < n) rc[j] = cand[k];
+      }
     }
   }
-  __syncthreads();
   OSTAMP(0);
 
   // ---- B. root nodes (ORBextractor.cc:541-585) ----
@@ -771,13 +811,12 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   const int Hrect = G.maxBorderY - ORB_MIN_BORDER;
   for (int i = tid; i < nIni; i += NT) chcnt[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += NT) {
-    uint32_t c = cand[k];
+  for_keys(n, [&](int, uint32_t &c, uint32_t &nd) {
     int r = (int)((float)(c & 0xfff) / hX);  // vpIniNodes[kp.pt.x/hX], :567
     r = min(max(r, 0), nIni - 1);
-    knode[k] = (uint16_t)r;
+    nd = (uint32_t)r;
     atomicAdd(&chcnt[r], 1u);
-  }
+  });
   __syncthreads();
   if (tid == 0) {
     int L = 0;
@@ -798,7 +837,7 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     shI[0] = L;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += NT) knode[k] = (uint16_t)chpos[knode[k]];
+  for_keys(n, [&](int, uint32_t &, uint32_t &nd) { nd = (uint32_t)chpos[nd]; });
   int L = shI[0];
   __syncthreads();
   OSTAMP(1);
@@ -814,17 +853,15 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     if (tid == 0) { shI[1] = 0; shI[2] = 0x7fffffff; }
     __syncthreads();
     // child key counts of every expandable node
-    for (int k = tid; k < n; k += NT) {
-      int nd = knode[k];
+    for_keys(n, [&](int, uint32_t &c, uint32_t &nd) {
       if (cnts[nd] > 1) {
         OctNode o = nodes[nd];
-        uint32_t c = cand[k];
         int x = c & 0xfff, y = (c >> 12) & 0xfff;
         int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;  // ceil(/2), :481-482
         int q = (x < o.ulx + hx ? 0 : 1) + (y < o.uly + hy ? 0 : 2);
         atomicAdd(&chcnt[nd * 4 + q], 1u);
       }
-    }
+    });
     __syncthreads();
     OSTAMP(2);
     // A full round (every node with more than one key is split, in list order: rank order = list order) needs three prefix sums
@@ -965,19 +1002,17 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
     __syncthreads();
     OSTAMP(4);
     // re-label the keys
-    for (int k = tid; k < n; k += NT) {
-      int nd = knode[k];
+    for_keys(n, [&](int, uint32_t &c, uint32_t &nd) {
       int np = npos[nd];
       if (np < 0) {
         OctNode o = nodes[nd];
-        uint32_t c = cand[k];
         int x = c & 0xfff, y = (c >> 12) & 0xfff;
         int hx = (o.urx - o.ulx + 1) >> 1, hy = (o.bry - o.uly + 1) >> 1;
         int q = (x < o.ulx + hx ? 0 : 1) + (y < o.uly + hy ? 0 : 2);
         np = chpos[nd * 4 + q];
       }
-      knode[k] = (uint16_t)np;
-    }
+      nd = (uint32_t)(uint16_t)np;
+    });
     const int nToExpand = shI[1];
     __syncthreads();
     OSTAMP(5);
@@ -991,24 +1026,25 @@ __global__ __launch_bounds__(NT) void k_octree(FrameParams P, uint32_t *cellOffS
   // ---- D. best key per node, list order out, lapping ranks (ORBextractor.cc:742-758, :1169-1178) ----
   for (int i = tid; i < L; i += NT) best[i] = 0ull;
   __syncthreads();
-  for (int k = tid; k < n; k += NT) {
-    uint32_t c = cand[k];
-    unsigned long long key = ((unsigned long long)(c >> 24) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k);
-    atomicMax(&best[knode[k]], key);
-  }
+  for_keys(n, [&](int k, uint32_t &c, uint32_t &nd) {
+    const unsigned long long key = ((unsigned long long)(c >> 24) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k);
+    atomicMax(&best[nd], key);
+  });
   __syncthreads();
   uint32_t *lkp = P.lkp + (size_t)frame * P.lkp_fs + G.kpBase;
   uint16_t *lrank = P.lrank + (size_t)frame * P.lkp_fs + G.kpBase;
   const int Lout = min(L, G.kpCap);
-  for (int i = tid; i < Lout; i += NT) {
-    uint32_t k = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
-    uint32_t c = cand[k];
-    lkp[i] = c;
-    float xs = (float)((int)(c & 0xfff) + ORB_MIN_BORDER);
-    if (level != 0) xs = xs * G.scale;  // keypoint->pt *= scale, :1164-1166
-    bool lap = xs >= (float)P.lap0 && xs <= (float)P.lap1;
-    sflag[i] = lap ? 1u : 0u;
-  }
+  // every node holds at least one key and exactly one key equals its maximum: that key's thread writes the node's keypoint
+  for_keys(n, [&](int k, uint32_t &c, uint32_t &nd) {
+    const unsigned long long key = ((unsigned long long)(c >> 24) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k);
+    if ((int)nd < Lout && best[nd] == key) {
+      lkp[nd] = c;
+      float xs = (float)((int)(c & 0xfff) + ORB_MIN_BORDER);
+      if (level != 0) xs = xs * G.scale;  // keypoint->pt *= scale, :1164-1166
+      const bool lap = xs >= (float)P.lap0 && xs <= (float)P.lap1;
+      sflag[nd] = lap ? 1u : 0u;
+    }
+  });
   __syncthreads();
   // sflag was read as packed flags; keep a copy of the flag in incl before the scan overwrites it
   for (int i = tid; i < Lout; i += NT) incl[i] = sflag[i];

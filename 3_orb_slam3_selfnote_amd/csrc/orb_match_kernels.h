@@ -60,7 +60,13 @@ struct MatchProblemSet {
 // ---------------------------------------------------------------------------------------------------------------
 #define MATCH_TOPK 8
 #define MATCH_CH 128
-#define RESOLVE_NW 8
+// Wavefronts of a k_match_resolve workgroup.  The resolver itself is ONE wavefront (the claims are sequential); the others only serve its
+// list requests.  Four, not eight: the fused form needs 248 vector registers per lane, so a workgroup of eight wavefronts (two per SIMD) took
+// the whole register file of its CU and nothing of the other pipelines could run beside it for the kernel's 0.3 ms - one workgroup per CU,
+// 256 frame pairs = every CU of the chip.  With one wavefront per SIMD half the registers stay free (four k_fast wavefronts per SIMD): alone
+// the kernel is 5 % slower (0.281 -> 0.296 ms, the list build is spread over half the wavefronts), the four-pipeline bench 5 % faster
+// (190.8 k -> 200.5 k frames/s); two wavefronts: 0.39 ms, 193 k.
+#define RESOLVE_NW 4
 
 struct Key32 {
   typedef uint32_t T;
@@ -955,7 +961,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   __shared__ int sVoteR;
   constexpr bool WIDE_OK = sizeof(K) == 4;   // Key32 only: frames of at most 2048 keypoints (the wide list array is 16 KiB)
   constexpr int WN = 64 * RESOLVE_NW;
-  __shared__ __align__(16) K sTkW[WIDE_OK ? MATCH_TOPK * WN : 1];
+  constexpr int TKW_WORDS = FUSED && MATCH_TOPK * WN < 3072 ? 3072 : MATCH_TOPK * WN;   // the fused form's work areas live in it as well
+  __shared__ __align__(16) K sTkW[WIDE_OK ? TKW_WORDS : 1];
   __shared__ int sRmin[4], sChg[4], sTake, sNm;   // sRmin / sChg: a ring over the rounds (see below)
   bool wide = false;
   if (FUSED && fusedPair) wide = false;   // fused pairs take the chunked form below
@@ -1152,8 +1159,8 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   }
   // ---- FUSED: lists on the matrix pipe (see the comment above the kernel).  Work areas in the wide form's list array, which a fused
   // pair does not use: [request descriptors 64 x 8 words][shares 64 x 8 wavefronts x 4 keys][compacted positions 8 x 256 u16][seeds 8 x 32]
-  constexpr int CMP_CAP = 256;                                // a wavefront's eighth of at most 2048 keypoints
-  static_assert(!FUSED || (64 * 8 + 64 * RESOLVE_NW * REFRESH_K + RESOLVE_NW * CMP_CAP / 2 + RESOLVE_NW * MF_TILE) * 4 <= MATCH_TOPK * WN * (int)sizeof(K), "work areas exceed the list array");
+  constexpr int CMP_CAP = 2048 / RESOLVE_NW;                  // a wavefront's share of at most 2048 keypoints
+  static_assert(!FUSED || (64 * 8 + 64 * RESOLVE_NW * REFRESH_K + RESOLVE_NW * CMP_CAP / 2 + RESOLVE_NW * MF_TILE) * 4 <= TKW_WORDS * (int)sizeof(K), "work areas exceed the list array");
   uint32_t *sReqD = reinterpret_cast<uint32_t *>(sTkW);
   uint32_t *sPartF = sReqD + 64 * 8;
   uint16_t *sCmpF = reinterpret_cast<uint16_t *>(sPartF + 64 * RESOLVE_NW * REFRESH_K);
