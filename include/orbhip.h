@@ -540,8 +540,10 @@ int orbm_set_scan_mode(orbm_t *m, int mode);
  *   1  open-window query blocks as exact int8 dot products on the matrix pipe (k_match_scan_mfma: monocular frames of at most
  *      2048 keypoints, batch launches);
  *   2  (default) as 1, and frame pairs ALL of whose queries are open build their candidate lists inside k_match_resolve (fused
- *      form): per 512-query super-chunk, with every keypoint a committed claim holds masked out, so that the lists cannot be
- *      exhausted by earlier claims (ORBmatcher.cc:89-91, :124-130 resolved without the refresh passes).
+ *      form): per 64-query chunk, at the chunk's turn, with every keypoint a committed claim holds masked out, so that the lists
+ *      are not exhausted by earlier chunks' claims (ORBmatcher.cc:89-91, :124-130 resolved without the refresh passes).
+ * Engines 1 and 2 also put the two brute-force entries on the matrix pipe: orbm_hamming_matrix (k_hamming_matrix_mfma) and
+ * orbm_knn_match2 (k_knn2_mfma, train sets below 2^20 descriptors); engine 0 keeps their vector-ALU kernels.
  * Results do not depend on it; the tests run all three. */
 int orbm_set_hamming_engine(orbm_t *m, int engine);
 
