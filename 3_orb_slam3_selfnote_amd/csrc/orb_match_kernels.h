@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   // ---- Wide form (tracking-sized windows, monocular / rectified-stereo problems) ------------------------------------------------------
   // The chunked form below resolves 64 queries at a time on ONE wavefront: with sparse conflicts its time is the number of
   // chunks times (a dozen global loads + two or three rounds of LDS round trips), all of it latency on a single wavefront while
-  // seven wait.  The same fix-point holds for any number of lanes: here every thread of the workgroup is a lane (512 queries per
+  // seven wait.  The same fix-point holds for any number of lanes: here every thread of the workgroup is a lane (64 * RESOLVE_NW queries per
   // super-chunk), "claimed for me" is still owner <= my index, a round is separated by workgroup barriers instead of wavefront
   // ones, and the settled prefix / first exhausted lane are found through two LDS words.  Conflict chains are short, so a
   // super-chunk settles in three or four rounds - a 1000-query frame in 8 rounds instead of 48.  Exhausted lists are refreshed
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   bool wide = false;
   if (FUSED && fusedPair) wide = false;   // fused pairs take the chunked form below
   else if (WIDE_OK && !M.serial && !M.partner && M.couple == 0 && !M.qside && rforce != SCAN_DENSE) {
-    wide = pair_walks<WN>(M, p, n, nq, rforce, &sVoteR);   // k_match_walk's rule, voted by this kernel's 512 threads
+    wide = pair_walks<WN>(M, p, n, nq, rforce, &sVoteR);   // k_match_walk's rule, voted by this kernel's threads
   }
   if (wide) {
     if (tid == 0) { for (int i = 0; i < 4; i++) { sRmin[i] = 0x7fffffff; sChg[i] = 0; } sTake = 0; sNm = 0; }
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     return;
   }
   // ---- FUSED: lists on the matrix pipe (see the comment above the kernel).  Work areas in the wide form's list array, which a fused
-  // pair does not use: [request descriptors 64 x 8 words][shares 64 x 8 wavefronts x 4 keys][compacted positions 8 x 256 u16][seeds 8 x 32]
+  // pair does not use: [request descriptors 64 x 8 words][shares 64 x RESOLVE_NW wavefronts x 4 keys][compacted positions RESOLVE_NW x CMP_CAP u16][seeds RESOLVE_NW x 32]
   constexpr int CMP_CAP = 2048 / RESOLVE_NW;                  // a wavefront's share of at most 2048 keypoints
   static_assert(!FUSED || (64 * 8 + 64 * RESOLVE_NW * REFRESH_K + RESOLVE_NW * CMP_CAP / 2 + RESOLVE_NW * MF_TILE) * 4 <= TKW_WORDS * (int)sizeof(K), "work areas exceed the list array");
   uint32_t *sReqD = reinterpret_cast<uint32_t *>(sTkW);

@@ -29,12 +29,12 @@
 // What is left on the VALU is the selection: every key goes through a branch-free sorted insertion, 1 v_min + (K - 1) v_med3
 // (new[j] = med3(top[j-1], top[j], t): independent instructions, half the count of a compare-exchange chain).
 //
-// Two users.  k_match_scan_mfma (orb_match_mfma.h): 256-query blocks whose live queries are ALL "open" (window = whole grid, no
+// Users.  The brute-force entries (k_hamming_matrix_mfma, k_knn2_mfma: orb_match_mfma.h) take the product as it is.  k_match_scan_mfma (orb_match_mfma.h): 256-query blocks whose live queries are ALL "open" (window = whole grid, no
 // level filter; query_is_open) of monocular problems on frames of at most 2048 keypoints get their top-8 lists from it and
 // k_match_scan skips exactly those blocks (same vote); the lists are the same Key32 lists either way.  k_match_resolve's FUSED
-// form (orb_match_kernels.h): frame pairs all of whose queries are open build the lists of a 512-query super-chunk inside the
+// form (orb_match_kernels.h): frame pairs all of whose queries are open build the lists of each 64-query chunk inside the
 // resolve kernel, with every keypoint a committed claim holds masked out through its accumulator seed - a list made that way
-// cannot be exhausted by the claims of earlier super-chunks, which is what the refresh passes of the separate-kernel form
+// cannot be exhausted by the claims of earlier chunks, which is what the refresh passes of the separate-kernel form
 // spent their time on.
 #pragma once
 #include <hip/hip_runtime.h>
