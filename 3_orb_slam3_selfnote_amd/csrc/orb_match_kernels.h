@@ -65,8 +65,9 @@ struct MatchProblemSet {
 // the whole register file of its CU and nothing of the other pipelines could run beside it for the kernel's 0.3 ms - one workgroup per CU,
 // 256 frame pairs = every CU of the chip.  With one wavefront per SIMD half the registers stay free (four k_fast wavefronts per SIMD): alone
 // the kernel is 5 % slower (0.281 -> 0.296 ms, the list build is spread over half the wavefronts), the four-pipeline bench 5 % faster
-// (190.8 k -> 200.5 k frames/s); two wavefronts: 0.39 ms, 193 k.
-#define RESOLVE_NW 4
+// (190.8 k -> 200.5 k frames/s); two wavefronts: 0.39 ms, 193 k.  The other forms (115-119 registers: two wavefronts per SIMD leave half the file
+// free as well) keep eight: the wide form's lanes ARE the workgroup's threads (512 queries per super-chunk).
+#define RESOLVE_NW_OF(fused) ((fused) ? 4 : 8)
 
 struct Key32 {
   typedef uint32_t T;
@@ -739,7 +740,7 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 // prefix final.  Conflicts are sparse, so a prefix settles in two or three rounds instead of one turn per query.
 // A lane whose list is exhausted (decide(): an unlisted keypoint could change its decision) cuts the prefix: everything
 // before it is committed, then the lane - together with every other exhausted lane, one wavefront each, up to
-// RESOLVE_NW at a time - gets a FRESH list: the REFRESH_K best keypoints of its window that no committed claim holds,
+// NW_ at a time - gets a FRESH list: the REFRESH_K best keypoints of its window that no committed claim holds,
 // found by scanning only the grid columns the window touches (sPerm = keypoints sorted by grid column, sCol = column
 // starts).  A list is valid as long as it was the head of the unclaimed candidates when it was made - later claims
 // are seen through sOwner - so refreshing is always safe, and right after it the lane is first in line and decides.
@@ -763,15 +764,16 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 // a key's low 11 bits are the position and sPerm gives the index.  What this replaces: the all-pairs scan kernel (0.23 ms per 256
 // frame pairs) and the 36 refresh passes per pair that re-scanned the frame on the vector ALU (70 % of k_match_resolve's 0.29 ms).
 template <typename KT, bool LDSCAND, bool FUSED = false>
-__global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn, int rforce,
+__global__ __launch_bounds__(64 * RESOLVE_NW_OF(FUSED)) void k_match_resolve(MatchProblemSet M, const typename KT::T *topk, int maxn, int rforce,
                                                                    const uint32_t *rec = nullptr, const uint32_t *keyrec = nullptr, const uint32_t *pairflag = nullptr) {
+  constexpr int NW_ = RESOLVE_NW_OF(FUSED);   // wavefronts of this workgroup (see RESOLVE_NW_OF)
   typedef typename KT::T K;
   extern __shared__ __align__(16) uint32_t smem_resolve[];
   __shared__ K sTk[MATCH_TOPK * 64];
   __shared__ int sCol[66 + 66];  // column starts (65 bins + end), then the scatter cursors
   __shared__ int sCmd;           // number of refresh requests posted, -1 = exit
-  __shared__ uint32_t sReq[RESOLVE_NW][REQ_WORDS];
-  __shared__ K sPart[RESOLVE_NW][RESOLVE_NW][REFRESH_K];   // [request][share]: each serving wavefront's REFRESH_K best keys
+  __shared__ uint32_t sReq[NW_][REQ_WORDS];
+  __shared__ K sPart[NW_][NW_][REFRESH_K];   // [request][share]: each serving wavefront's REFRESH_K best keys
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int p = blockIdx.x;
   const int n = M.frame_n ? M.frame_n[(size_t)p * M.frame_n_stride] : M.frame_n_const;
@@ -794,9 +796,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   bool fusedPair = false;
   if constexpr (FUSED) fusedPair = pairflag[p] != 0u;
   int *sFill = sCol + 66;
-  for (int i = tid; i < 132; i += 64 * RESOLVE_NW) sCol[i] = 0;
+  for (int i = tid; i < 132; i += 64 * NW_) sCol[i] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+  for (int i = tid; i < n; i += 64 * NW_) {
     sOwner[i] = (slot[i] >= 0 && slot_obs[i]) ? 0u : RESOLVE_FREE;
     sSlot[i] = -1;
     const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
@@ -806,14 +808,14 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   }
   if (tid == 0) sOwner[n] = RESOLVE_FREE;
   if (M.partner)
-    for (int i = tid; i < n; i += 64 * RESOLVE_NW) { const int32_t pr = M.partner[fo + i]; sPartner[i] = (uint16_t)(pr >= 0 && pr < n ? pr : 0xffff); }
+    for (int i = tid; i < n; i += 64 * NW_) { const int32_t pr = M.partner[fo + i]; sPartner[i] = (uint16_t)(pr >= 0 && pr < n ? pr : 0xffff); }
   __syncthreads();
   if (tid == 0) {  // exclusive prefix: sCol[c] = first position of column c, sCol[64] = end of the in-grid keypoints
     int acc = 0;
     for (int c = 1; c <= 65; c++) { acc += sCol[c]; sCol[c] = acc; }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+  for (int i = tid; i < n; i += 64 * NW_) {
     const float x = kp[(size_t)i * 7], y = kp[(size_t)i * 7 + 1];
     const uint32_t bits = cand_bits(x, y, __float_as_int(kp[(size_t)i * 7 + 5]), false, M);
     const int col = ((bits >> 24) & 1u) ? (int)((bits >> 8) & 0xff) : 64;
@@ -842,10 +844,10 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   };
   // One wavefront serves refresh request `rq`: the REFRESH_K smallest keys of the query's window among the keypoints
   // no committed claim holds -> column `target lane` of sTk.
-  // A pass serves m <= RESOLVE_NW requests with all RESOLVE_NW wavefronts: mp = m rounded up to a power of two, every request
-  // gets RESOLVE_NW / mp wavefronts, each scanning an interleaved share of the window's keypoints; the requesting lane merges
+  // A pass serves m <= NW_ requests with all NW_ wavefronts: mp = m rounded up to a power of two, every request
+  // gets NW_ / mp wavefronts, each scanning an interleaved share of the window's keypoints; the requesting lane merges
   // the shares' sorted lists.  Most passes carry one or two requests, which then finish 8 or 4 times sooner.
-  auto shares_of = [](int m) { return m <= 1 ? RESOLVE_NW : m <= 2 ? RESOLVE_NW / 2 : m <= 4 ? RESOLVE_NW / 4 : 1; };
+  auto shares_of = [](int m) { return m <= 1 ? NW_ : m <= 2 ? NW_ / 2 : m <= 4 ? NW_ / 4 : 1; };
   auto serve = [&](int rq, int part, int nparts) {
     const uint32_t *R = sReq[rq];
     const int target = (int)R[0];
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   // ---- Wide form (tracking-sized windows, monocular / rectified-stereo problems) ------------------------------------------------------
   // The chunked form below resolves 64 queries at a time on ONE wavefront: with sparse conflicts its time is the number of
   // chunks times (a dozen global loads + two or three rounds of LDS round trips), all of it latency on a single wavefront while
-  // seven wait.  The same fix-point holds for any number of lanes: here every thread of the workgroup is a lane (64 * RESOLVE_NW queries per
+  // seven wait.  The same fix-point holds for any number of lanes: here every thread of the workgroup is a lane (64 * NW_ queries per
   // super-chunk), "claimed for me" is still owner <= my index, a round is separated by workgroup barriers instead of wavefront
   // ones, and the settled prefix / first exhausted lane are found through two LDS words.  Conflict chains are short, so a
   // super-chunk settles in three or four rounds - a 1000-query frame in 8 rounds instead of 48.  Exhausted lists are refreshed
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
   // passes are cheaper per pass.
   __shared__ int sVoteR;
   constexpr bool WIDE_OK = sizeof(K) == 4;   // Key32 only: frames of at most 2048 keypoints (the wide list array is 16 KiB)
-  constexpr int WN = 64 * RESOLVE_NW;
+  constexpr int WN = 64 * NW_;
   constexpr int TKW_WORDS = FUSED && MATCH_TOPK * WN < 3072 ? 3072 : MATCH_TOPK * WN;   // the fused form's work areas live in it as well
   __shared__ __align__(16) K sTkW[WIDE_OK ? TKW_WORDS : 1];
   __shared__ int sRmin[4], sChg[4], sTake, sNm;   // sRmin / sChg: a ring over the rounds (see below)
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         if (!(myfl & 1u)) { vm = 0; truncated = false; }
       };
       load_list();
-      // fresh lists for every lane with `want`, RESOLVE_NW requests per pass, all wavefronts serving (serve() as in the chunked form)
+      // fresh lists for every lane with `want`, NW_ requests per pass, all wavefronts serving (serve() as in the chunked form)
       auto refresh = [&](bool want) {
         bool todo = want;
         WSTMP(ws_round);
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           __syncthreads();                       // sTake == 0 here (reset at the end of the previous pass / at start)
           int slot = -1;
           if (todo) slot = atomicAdd(&sTake, 1);
-          const bool take = todo && slot < RESOLVE_NW;
+          const bool take = todo && slot < NW_;
           if (take) {
             uint32_t *R = sReq[slot];
             R[0] = (uint32_t)tid; R[1] = myfl;
@@ -1039,9 +1041,9 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
           __syncthreads();
           const int asked = sTake;
           if (asked == 0) break;                 // uniform: nobody left
-          const int m = min(RESOLVE_NW, asked);
+          const int m = min(NW_, asked);
           {
-            const int np = shares_of(m), mp = RESOLVE_NW / np, rq = wid & (mp - 1);
+            const int np = shares_of(m), mp = NW_ / np, rq = wid & (mp - 1);
             if (rq < m) serve(rq, wid / mp, np);
           }
           __syncthreads();
@@ -1151,25 +1153,25 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     if (lane == 0 && nmatches) atomicAdd(&sNm, nmatches);
     __syncthreads();
     if (tid == 0 && M.nmatches) M.nmatches[p] = sNm;
-    for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+    for (int i = tid; i < n; i += 64 * NW_) {
       const int32_t v = sSlot[i];
       if (v >= 0) { slot[i] = v >> 1; slot_obs[i] = (uint8_t)(v & 1); }
     }
     return;
   }
   // ---- FUSED: lists on the matrix pipe (see the comment above the kernel).  Work areas in the wide form's list array, which a fused
-  // pair does not use: [request descriptors 64 x 8 words][shares 64 x RESOLVE_NW wavefronts x 4 keys][compacted positions RESOLVE_NW x CMP_CAP u16][seeds RESOLVE_NW x 32]
-  constexpr int CMP_CAP = 2048 / RESOLVE_NW;                  // a wavefront's share of at most 2048 keypoints
-  static_assert(!FUSED || (64 * 8 + 64 * RESOLVE_NW * REFRESH_K + RESOLVE_NW * CMP_CAP / 2 + RESOLVE_NW * MF_TILE) * 4 <= TKW_WORDS * (int)sizeof(K), "work areas exceed the list array");
+  // pair does not use: [request descriptors 64 x 8 words][shares 64 x NW_ wavefronts x 4 keys][compacted positions NW_ x CMP_CAP u16][seeds NW_ x 32]
+  constexpr int CMP_CAP = 2048 / NW_;                  // a wavefront's share of at most 2048 keypoints
+  static_assert(!FUSED || (64 * 8 + 64 * NW_ * REFRESH_K + NW_ * CMP_CAP / 2 + NW_ * MF_TILE) * 4 <= TKW_WORDS * (int)sizeof(K), "work areas exceed the list array");
   uint32_t *sReqD = reinterpret_cast<uint32_t *>(sTkW);
   uint32_t *sPartF = sReqD + 64 * 8;
-  uint16_t *sCmpF = reinterpret_cast<uint16_t *>(sPartF + 64 * RESOLVE_NW * REFRESH_K);
-  uint32_t *sSeedF = reinterpret_cast<uint32_t *>(sCmpF + RESOLVE_NW * CMP_CAP);
+  uint16_t *sCmpF = reinterpret_cast<uint16_t *>(sPartF + 64 * NW_ * REFRESH_K);
+  uint32_t *sSeedF = reinterpret_cast<uint32_t *>(sCmpF + NW_ * CMP_CAP);
   auto serve_mfma = [&](int m) {   // all wavefronts; m <= 64 requests posted in sReqD (their queries are open: every usable keypoint is a candidate)
     if constexpr (FUSED) {
       const int col = lane & 31, h = lane >> 5;
       const int nin = sCol[64];                               // the keypoints PosInGrid accepts are positions [0, nin)
-      const int lo = (int)(((long long)nin * wid) / RESOLVE_NW), hi = (int)(((long long)nin * (wid + 1)) / RESOLVE_NW);
+      const int lo = (int)(((long long)nin * wid) / NW_), hi = (int)(((long long)nin * (wid + 1)) / NW_);
       uint16_t *cmp = sCmpF + wid * CMP_CAP;
       int kw = 0;
       for (int b0 = lo; b0 < hi; b0 += 64) {                  // my eighth, compacted to the keypoints no committed claim holds
@@ -1237,18 +1239,18 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       cxu(mg[0], mg[2]); cxu(mg[1], mg[3]);
       cxu(mg[0], mg[1]); cxu(mg[2], mg[3]);
       const int req = h * 32 + col;
-      if (req < m) *reinterpret_cast<uint4 *>(sPartF + ((size_t)req * RESOLVE_NW + wid) * REFRESH_K) = make_uint4(mg[0], mg[1], mg[2], mg[3]);
+      if (req < m) *reinterpret_cast<uint4 *>(sPartF + ((size_t)req * NW_ + wid) * REFRESH_K) = make_uint4(mg[0], mg[1], mg[2], mg[3]);
     }
   };
-  // requesting lane: fold the RESOLVE_NW sorted shares of request `rank`, turn the keys (distance << 11 | position) into list entries
+  // requesting lane: fold the NW_ sorted shares of request `rank`, turn the keys (distance << 11 | position) into list entries
   auto fold_mfma = [&](int rank, K *colp /* column of the chunk's list array, stride 64 */) {
     if constexpr (FUSED) {
       auto cxu = [](uint32_t &a, uint32_t &b) { const uint32_t l = min(a, b), g2 = max(a, b); a = l; b = g2; };
-      const uint4 *sh = reinterpret_cast<const uint4 *>(sPartF + (size_t)rank * RESOLVE_NW * REFRESH_K);
+      const uint4 *sh = reinterpret_cast<const uint4 *>(sPartF + (size_t)rank * NW_ * REFRESH_K);
       uint4 v = sh[0];
       uint32_t a[REFRESH_K] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int w2 = 1; w2 < RESOLVE_NW; w2++) {
+      for (int w2 = 1; w2 < NW_; w2++) {
         v = sh[w2];
         a[0] = min(a[0], v.w); a[1] = min(a[1], v.z); a[2] = min(a[2], v.y); a[3] = min(a[3], v.x);
         cxu(a[0], a[2]); cxu(a[1], a[3]);
@@ -1274,7 +1276,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
       if (m < 0) break;
       if (FUSED && fusedPair) serve_mfma(m);
       else {
-        const int np = shares_of(m), mp = RESOLVE_NW / np, rq = wid & (mp - 1);
+        const int np = shares_of(m), mp = NW_ / np, rq = wid & (mp - 1);
         if (rq < m) serve(rq, wid / mp, np);
       }
       __syncthreads();                 // (B) shares written
@@ -1332,7 +1334,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         if (!(myfl & 1u)) { vm = 0; truncated = false; }   // dropped query (scan may have listed candidates for it)
       };
       load_list();
-      // refresh the lists of the lanes in F, RESOLVE_NW per pass (one wavefront each)
+      // refresh the lists of the lanes in F, NW_ per pass (one wavefront each)
       auto refresh = [&](unsigned long long F) {
 #ifdef RESOLVE_STAMPS
         long long ts0 = __builtin_readcyclecounter(), ts1 = ts0;
@@ -1359,7 +1361,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
         }
         while (todo) {
           const int rank = __popcll(todo & ((1ull << lane) - 1ull));
-          const bool take = ((todo >> lane) & 1ull) && rank < RESOLVE_NW;
+          const bool take = ((todo >> lane) & 1ull) && rank < NW_;
           if (take) {
             uint32_t *R = sReq[rank];
             R[0] = (uint32_t)lane; R[1] = myfl;
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
 #pragma unroll
             for (int t = 0; t < 8; t++) R[8 + t] = qd[t];
           }
-          const int m = min(RESOLVE_NW, (int)__popcll(todo));
+          const int m = min(NW_, (int)__popcll(todo));
           if (lane == 0) sCmd = m;
 #ifdef RESOLVE_STAMPS
           long long tq = __builtin_readcyclecounter(); t_sub[0] += tq - ts1; ts1 = tq; sub_m += m;
@@ -1530,7 +1532,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW) void k_match_resolve(MatchProblemS
     __syncthreads();                   // (A) exit command
   }
   __syncthreads();                     // sSlot complete
-  for (int i = tid; i < n; i += 64 * RESOLVE_NW) {
+  for (int i = tid; i < n; i += 64 * NW_) {
     const int32_t v = sSlot[i];
     if (v >= 0) { slot[i] = v >> 1; slot_obs[i] = (uint8_t)(v & 1); }
   }

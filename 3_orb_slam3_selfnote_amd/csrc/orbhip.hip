@@ -1395,7 +1395,7 @@ int orbm_search_by_projection_batch_device(orbm_t *m, const orbm_frame_t *f, int
   const bool fused = mfma && m->hamming_engine >= 2 && init_th_low < 0 && !M.serial && M.couple == 0 && big + sizeof(uint32_t) * (size_t)maxn <= 138 * 1024;
   const size_t lds = fused ? big + sizeof(uint32_t) * (size_t)maxn : ldscand ? big : small;
   if (lds > 152 * 1024) { m->err = "too many keypoints per frame for the search kernels' LDS state (fisheye-stereo frames: at most 13000)"; return ORBX_E_ARG; }
-  const dim3 rblock(64 * RESOLVE_NW);
+  const dim3 rblock(64 * RESOLVE_NW_OF(fused));
   // Window walk (k_match_walk) or full scan (k_match_scan): decided per pair on the device unless a mode is forced; frames beyond
   // 2048 keypoints (Key64) are always scanned.  The walk's workgroups come first: they are the short ones.
   const int force = !k32 ? SCAN_DENSE : (m->next_scan_mode >= 0 ? m->next_scan_mode : m->scan_mode);
