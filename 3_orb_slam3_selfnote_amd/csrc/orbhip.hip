@@ -447,6 +447,7 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   for (int l = 0; l < nl; l++) {
     const LevelGeom &G = g[l];
     if (G.pitch > 65535 || G.bpitch > 65535) { h->err = "level pitch above 65535"; return ORBX_E_ARG; }
+    if (l > 0 && (size_t)((G.w + 3) & ~3) * 8 > ORB_LDS_LIMIT - 1024) { h->err = "pyramid level wider than 20000 columns"; return ORBX_E_ARG; }   // k_resize's x table
     for (int ty = 0; ty < G.tilesY; ty++)
       for (int tx = 0; tx < G.tilesX; tx++) {
         uint32_t *R = &tilerec[(size_t)(G.tileBase + ty * G.tilesX + tx) * 8];
@@ -652,9 +653,11 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     // precondition holds (two neighbouring columns' source bytes inside one aligned 8-byte window: horizontal scale factor below 3);
     // otherwise the one-pass form straight from global memory (tPitch 0), which stages the x table only.
     const int wq = (G.w + 3) & ~3;
-    const bool twoPass = G.resizeSrcRows <= RESIZE_MAXSRC && (double)Gs.w / G.w < 3.0;
-    const int tPitch = twoPass ? (int)align_up((size_t)wq * 2, 8) : 0;     // horizontally interpolated rows, 16 bits per column
-    const size_t lds = twoPass ? (size_t)G.resizeSrcRows * (rowBytes + tPitch) + 16 * RESIZE_ROWS : (size_t)wq * 8;
+    const int tPitch2 = (int)align_up((size_t)wq * 2, 8);                  // horizontally interpolated rows, 16 bits per column
+    const size_t lds2 = (size_t)G.resizeSrcRows * (rowBytes + tPitch2) + 16 * RESIZE_ROWS;
+    const bool twoPass = G.resizeSrcRows <= RESIZE_MAXSRC && (double)Gs.w / G.w < 3.0 && lds2 <= ORB_LDS_LIMIT - 1024;   // (very wide images: one-pass)
+    const int tPitch = twoPass ? tPitch2 : 0;
+    const size_t lds = twoPass ? lds2 : (size_t)wq * 8;
     hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch, G.resizeSrcRows);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
