@@ -756,10 +756,10 @@ __device__ __forceinline__ uint32_t decide(const MatchProblemSet &M, const typen
 #define REQ_WORDS 16  // lane, flags, u, v, r, ur, minl, maxl, descriptor[8]
 // FUSED (Key32, LDSCAND; orb_mfma_util.h): a frame pair ALL of whose live queries are open (pairflag[p], voted by k_match_rank) gets
 // no lists from the scan kernels.  It is resolved in the chunked form, and the lists of a chunk of 64 queries are made at the
-// chunk's turn by the whole workgroup on the matrix pipe (serve_mfma): every wavefront takes an eighth of the keypoints, keeps
+// chunk's turn by the whole workgroup on the matrix pipe (serve_mfma): every wavefront takes its share of the keypoints, keeps
 // only those NO COMMITTED CLAIM HOLDS (compacted, so the work shrinks as the frame fills up: by the last chunks nine keypoints in
 // ten are taken), runs them as 32-row A tiles against the chunk's queries (two B tiles built from the posted descriptors) with
-// the keypoint's rank as accumulator seed, and keeps a top-4 per query and wavefront; the requesting lane folds the eight sorted
+// the keypoint's rank as accumulator seed, and keeps a top-4 per query and wavefront; the requesting lane folds the wavefronts' sorted
 // shares.  The same pass serves the (now rare) lists exhausted inside a chunk.  The keypoints sit in LDS at position = rank, so
 // a key's low 11 bits are the position and sPerm gives the index.  What this replaces: the all-pairs scan kernel (0.23 ms per 256
 // frame pairs) and the 36 refresh passes per pair that re-scanned the frame on the vector ALU (70 % of k_match_resolve's 0.29 ms).
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(64 * RESOLVE_NW_OF(FUSED)) void k_match_resolve(Mat
       const int lo = (int)(((long long)nin * wid) / NW_), hi = (int)(((long long)nin * (wid + 1)) / NW_);
       uint16_t *cmp = sCmpF + wid * CMP_CAP;
       int kw = 0;
-      for (int b0 = lo; b0 < hi; b0 += 64) {                  // my eighth, compacted to the keypoints no committed claim holds
+      for (int b0 = lo; b0 < hi; b0 += 64) {                  // my share, compacted to the keypoints no committed claim holds
         const int pos = b0 + lane;
         bool keep = false;
         if (pos < hi) keep = !(sRank[pos] & MF_REC_HELD) && sOwner[sPerm[pos]] != 0u;
