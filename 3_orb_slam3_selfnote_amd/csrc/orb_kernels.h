@@ -438,7 +438,7 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
   ORB_RING(8, -3 * Pt)      ORB_RING(9, -3 * Pt - 1)  ORB_RING(10, -2 * Pt - 2)  ORB_RING(11, -1 * Pt - 3)
   ORB_RING(12, -3)          ORB_RING(13, 1 * Pt - 3)  ORB_RING(14, 2 * Pt - 2)   ORB_RING(15, 3 * Pt - 1)
 #undef ORB_RING
-  // sliding window minimum of length 9 on the circular sequence by doubling: 2, 4, 8, then +1
+  // sliding window minimum of length 9 on the circular sequence by doubling: 2, 4, then three windows of 4 (k, k+4, k+5)
   pk16 m2[16], m4[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
@@ -447,7 +447,7 @@ __device__ __forceinline__ int fast_score_S(const uint8_t *c /* tile centre, pit
   pk16 A = {(short)-255, (short)-255};
 #pragma unroll
   for (int k = 0; k < 16; k++)
-    A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+    A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), m4[(k + 5) & 15]));   // k .. k+8: the third window overlaps the second, so d and m2 are dead by now (registers)
   const int S = max((int)A.x, (int)A.y);  // all of some arc darker by A.x, or brighter by A.y
   return min(max(S, 0), 255);
 }
