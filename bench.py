@@ -23,8 +23,8 @@ Extra keys on the JSON line:
   roofline         dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the launch stream,
                    measured over the timed region; see also profiles/), against the 8 TB/s HBM peak; `valu_issue`: the step's vector
                    instructions per second against the MEASURED issue ceiling of its opcode mix (profiles/valu_calib.json)
-  verified_frames  frames of the LAST TIMED STEP whose keypoints, descriptors and match indices are byte-equal to the CPU oracle's
-                   (non-zero exit status on any mismatch)
+  verified_frames  frames of the last timed batch of EVERY pipeline (streams x batch frames, distinct frame sets) whose keypoints,
+                   descriptors and match indices are byte-equal to the CPU oracle's (non-zero exit status on any mismatch)
   cpu_baseline     the CPU oracle (oracle/, kind "port") timed natively on this host per BASELINE.md section 3: one core and all
                    cores (one frame per thread), median and mean, extract / match split (rank 0, N=1 only)
   host_fed         the same pipeline fed from pinned host memory (all frame sets in turn; H2D on a copy stream ahead of the pipelines, D2H
@@ -147,21 +147,26 @@ def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=
     frames, offs = groups[g_last]
     B = len(frames)
     r1 = O.bench_stream(ex, frames, offs, B, threads=1, warmup=50, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100, scene=scene_of(g_last), distort=distort)
-    # ---- parity tie: the last timed batch of the GPU against the oracle, frame by frame
+    # ---- parity tie: every pipeline's last timed batch against the oracle, frame by frame (the pipeline of the very last batch against
+    # the one-core run, the others against the all-cores run of their frame set, below)
     bad = []
-    verified = 0
-    for t in range(B):
-        n = int(r1["counts"][t, 0])
-        ok = n == int(gpu_last["cnt"][t, 0]) and int(r1["counts"][t, 1]) == int(gpu_last["cnt"][t, 1])
-        ok = ok and r1["kps"][t, :n].tobytes() == gpu_last["kps"][t, :n].tobytes() and np.array_equal(r1["desc"][t, :n], gpu_last["desc"][t, :n])
-        if ok and "match" in gpu_last:
-            nl = int(r1["counts"][(t - 1) % B, 0])
-            m = nl if mode == 0 else n           # mode 0: match_of_query of the last frame's keypoints; mode 1: slot array of the current frame
-            ok = int(r1["nmatch"][t]) == int(gpu_last["nm"][t]) and np.array_equal(r1["moq"][t, :m], gpu_last["match"][t, :m])
-        if ok:
-            verified += 1
-        else:
-            bad.append(t)
+    verified = [0]
+
+    def compare(r, got, tag):
+        for t in range(B):
+            n = int(r["counts"][t, 0])
+            ok = n == int(got["cnt"][t, 0]) and int(r["counts"][t, 1]) == int(got["cnt"][t, 1])
+            ok = ok and r["kps"][t, :n].tobytes() == got["kps"][t, :n].tobytes() and np.array_equal(r["desc"][t, :n], got["desc"][t, :n])
+            if ok and "match" in got:
+                nl = int(r["counts"][(t - 1) % B, 0])
+                m = nl if mode == 0 else n           # mode 0: match_of_query of the last frame's keypoints; mode 1: slot array of the current frame
+                ok = int(r["nmatch"][t]) == int(got["nm"][t]) and np.array_equal(r["moq"][t, :m], got["match"][t, :m])
+            if ok:
+                verified[0] += 1
+            else:
+                bad.append((tag, t))
+    assert gpu_last[0][0] == g_last
+    compare(r1, gpu_last[0][1], 0)
     tot1 = r1["ms_extract"] + r1["ms_match"]
     one = {"frames": B, "warmup_frames": 50, "extract_ms": stats_ms(r1["ms_extract"]), "match_ms": stats_ms(r1["ms_match"]), "total_ms": stats_ms(tot1),
            "fps": round(B / (r1["wall_extract"] + r1["wall_match"]), 3), "extract_fps": round(B / r1["wall_extract"], 3)}
@@ -172,12 +177,15 @@ def cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=
         ra = O.bench_stream(ex, fr, of, len(fr), threads=nthreads, warmup=nthreads if g == 0 else 0, lap=LAP, cap=cap, mode=mode, nnratio=0.8, th_high=100,
                             scene=scene_of(g), distort=distort)
         nfr += len(fr); we += ra["wall_extract"]; wm += ra["wall_match"]
+        for i in range(1, len(gpu_last)):
+            if gpu_last[i][0] == g:
+                compare(ra, gpu_last[i][1], i)
     allc = {"threads": nthreads, "frames": nfr, "fps": round(nfr / (we + wm), 3), "extract_fps": round(nfr / we, 3), "match_fps": round(nfr / wm, 3)}
     out = {"value": one["fps"], "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "oracle/liborb_oracle.so (gcc -O3 -ffp-contract=off), native timer around each call (orb_cpu_bench.c), same synthetic stream: "
                      "1 core: %d frames after 50 warm-up frames; %d threads, one frame per thread: %d frames" % (B, nthreads, nfr),
            "one_core": one, "all_cores": allc}
-    return out, verified, bad
+    return out, verified[0], bad
 
 
 def main():
@@ -342,7 +350,7 @@ def main():
     def step():
         for _ in range(NB):
             j = counter[0]
-            pipes[j % S].batch((j // S) % G, scene=scene_dev)
+            pipes[j % S].batch((j // S + j % S) % G, scene=scene_dev)     # neighbouring pipelines work on different frame sets
             counter[0] += 1
 
     def start_profiling():
@@ -369,16 +377,19 @@ def main():
     acc = {k: v / nsamp for k, v in acc.items()}
     # the last timed batch: what the parity tie compares
     j_last = counter[0] - 1
-    p_last, g_last = pipes[j_last % S], (j_last // S) % G
-    gpu_last = None
+    p_last, g_last = pipes[j_last % S], (j_last // S + j_last % S) % G
+    gpu_last = None      # what EVERY pipeline's last batch left in HBM: [(frame set, outputs)], the pipeline of the very last batch first
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        gpu_last = {"cnt": p_last.d_cnt[1:].cpu().numpy(), "kps": p_last.d_kps[1:].cpu().numpy().view(np.uint8).reshape(B, cap, 28),
-                    "desc": p_last.d_desc[1:].cpu().numpy()}
         from oracle import oracle_py as O
-        gpu_last["kps"] = gpu_last["kps"].reshape(B, cap * 28).view(O.KP_DTYPE).reshape(B, cap)
-        if not args.no_match:
-            gpu_last["nm"] = p_last.d_nm.cpu().numpy()
-            gpu_last["match"] = (p_last.d_slot if tumvi else p_last.d_moq).cpu().numpy()
+
+        def grab(pp):
+            o = {"cnt": pp.d_cnt[1:].cpu().numpy(), "desc": pp.d_desc[1:].cpu().numpy(),
+                 "kps": pp.d_kps[1:].cpu().numpy().view(np.uint8).reshape(B, cap * 28).view(O.KP_DTYPE).reshape(B, cap)}
+            if not args.no_match:
+                o["nm"] = pp.d_nm.cpu().numpy()
+                o["match"] = (pp.d_slot if tumvi else pp.d_moq).cpu().numpy()
+            return o
+        gpu_last = [(pp.group, grab(pp)) for pp in [p_last] + [q for q in pipes if q is not p_last and q.group >= 0]]
     cnt = p_last.d_cnt[1:].cpu().numpy()
     n_kp = float(cnt[:, 0].mean())
     nm_mean = float(p_last.d_nm.cpu().numpy().mean()) if not args.no_match else 0.0
@@ -574,7 +585,7 @@ def main():
             cb, verified, bad = cpu_legs(conf, groups, g_last, gpu_last, scene_host, cap, nthreads, distort=(EUROC_K, EUROC_D) if distort else None)
             out["cpu_baseline"] = cb
             out["verified_frames"] = verified
-            out["verified_of"] = B
+            out["verified_of"] = B * len(gpu_last)        # the last timed batch of every pipeline
             if bad:
                 out["verify_mismatch_frames"] = bad[:16]
                 rc = 3
