@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "orbx_get_scale_tables", "orbx_get_features_per_level", "orbx_configure", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch_device", "orbx_get_host_us", "orbx_level_info", "orbx_download_level", "orbx_download_pyramid", "orbx_download_blurred_level",
     "orbx_download_candidates", "orbx_download_level_keypoints", "orbx_set_profiling", "orbx_get_stage_ms",
-    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_calibration_copy", "orbx_calibration_valu_ops", "orbx_calibration_valu_name", "orbx_calibration_valu", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
+    "orbx_ref_cosf", "orbx_ref_sinf", "orbx_ref_atanf", "orbx_ref_atan2f", "orbx_compute_stereo_matches", "orbx_cvt_color_gray", "orbx_cvt_color_gray_device",
     "orbx_clahe", "orbx_clahe_device", "orbx_remap_linear", "orbx_remap_linear_device",
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_descriptor_distance", "orbm_search_by_projection",
     "orbm_search_by_projection_batch_device", "orbm_search_by_projection_fisheye", "orbm_search_by_projection_last_frame_fisheye", "orbm_search_by_projection_last_frame", "orbm_search_by_projection_last_frame_batch_device", "orbm_search_by_projection_keyframe", "orbm_search_by_projection_sim3", "orbm_search_by_projection_sim3_cam", "orbm_fuse_sim3_cam", "orbm_search_for_triangulation", "orbm_triangulation_candidates", "orbm_search_for_triangulation_pred", "orbm_search_for_initialization", "orbm_search_by_bow", "orbm_search_by_bow_fisheye", "orbm_search_by_bow_keyframes", "orbm_fuse", "orbm_fuse_sim3", "orbm_search_by_sim3", "orbm_distinctive_descriptors", "orbm_knn_match2", "orbm_hamming_matrix", "orbm_three_maxima",
@@ -109,11 +109,6 @@ def load(build_if_needed=True):
     L.orbx_download_level_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_get_stage_ms.argtypes = [vp, vp, i32]
-    L.orbx_calibration_copy.argtypes = [vp, vp, sz, vp]
-    L.orbx_calibration_valu_ops.argtypes = []
-    L.orbx_calibration_valu_name.restype = C.c_char_p
-    L.orbx_calibration_valu_name.argtypes = [i32]
-    L.orbx_calibration_valu.argtypes = [i32, i32, i32, i32, vp, vp, vp]
     L.orbx_compute_stereo_matches.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, f32, f32, vp, vp]
     L.orbx_cvt_color_gray.argtypes = [vp, vp, i32, i32, sz, i32, i32, vp, sz]
     L.orbx_cvt_color_gray_device.argtypes = [vp, i32, i32, sz, i32, i32, vp, sz, vp]

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liborbhip.so")
-SOURCES = ["orbhip.hip", "orb_kernels.h", "orb_match_kernels.h", "orb_match_mfma.h", "orb_mfma_util.h", "orb_common.h", "orb_sincos.h", "orb_calib.h", "orb_project_kernels.h", "orb_atan2f.h"]
+SOURCES = ["orbhip.hip", "orb_kernels.h", "orb_match_kernels.h", "orb_match_mfma.h", "orb_mfma_util.h", "orb_common.h", "orb_sincos.h", "orb_project_kernels.h", "orb_atan2f.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",

@@ -526,7 +526,7 @@ def main():
             traffic = None
 
     # VALU issue roofline of the whole batch: wave-instructions per launch from the committed SQ_INSTS_VALU profile (a separate
-    # rocprofv3 --pmc run of this workload, tools/collect_sq.py); the ceiling is MEASURED per opcode class by csrc/orb_calib.h
+    # rocprofv3 --pmc run of this workload, tools/collect_sq.py); the ceiling is MEASURED per opcode class by tools/calib/orb_calib.h
     # (profiles/valu_calib.json) and weighted with every kernel's own opcode mix (tools/valu_mix.py -> profiles/valu_mix.json).
     valu = None
     sfp, mixp = os.path.join(ROOT, "profiles", "sq_counters.json"), os.path.join(ROOT, "profiles", "valu_mix.json")

@@ -121,23 +121,6 @@ int orbx_get_host_us(const orbx_t *h, float *us, int cap);
 void orbx_set_profiling(orbx_t *h, int enable);
 int orbx_get_stage_ms(orbx_t *h, float *ms, int cap);
 
-/* Measurement aid: copies nbytes device->device with 4-byte-per-lane accesses (known HBM traffic: nbytes read +
- * nbytes written) so that the rocprofv3 FETCH_SIZE/WRITE_SIZE counters can be calibrated in this library's access
- * pattern (tools/collect_traffic.py). */
-int orbx_calibration_copy(const void *d_src, void *d_dst, size_t nbytes, void *stream);
-
-/* Measurement aid: the chip's vector-issue ceiling for one opcode class (csrc/orb_calib.h), the counterpart of
- * orbx_calibration_copy for bench.py's `valu_issue` roofline.  Runs a stream of independent instructions of class `op`
- * (0 <= op < orbx_calibration_valu_ops(); orbx_calibration_valu_name(op) names it) on every CU with `waves_per_simd` (1, 2, 4
- * or 8) resident wavefronts per SIMD, `trips` x 128 instructions per wavefront.  Out: wave-instructions per second of the
- * whole chip (HIP events), shader cycles one wave-instruction occupies its SIMD (s_memtime, median over workgroups) and the
- * shader clock held meanwhile in GHz (s_memtime / s_memrealtime).  Synchronous, default stream.  tools/collect_valu_calib.py
- * sweeps it into profiles/valu_calib.json. */
-int orbx_calibration_valu_ops(void);
-const char *orbx_calibration_valu_name(int op);
-int orbx_calibration_valu(int device, int op, int waves_per_simd, int trips, double *wave_instr_per_s, double *cycles_per_instr,
-                          double *clock_ghz);
-
 /* Device replica of the libm cosf/sinf the reference calls at ORBextractor.cc:111, exposed for the exhaustive
  * host-side check in tests (host evaluation of the same source the kernel compiles). */
 float orbx_ref_cosf(float x);

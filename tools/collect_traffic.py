@@ -4,8 +4,8 @@
 Follows /opt/skills/guides/MI355X_MICROARCH.md "HBM" + "rocprofv3 PMC slots": FETCH_SIZE and WRITE_SIZE do not fit one
 pass (TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2), so they are collected in SEPARATE runs with --pmc only
 (no --sys-trace / runtime trace).  Units: the counters are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced
-reads by 2x and other widths are uncalibrated, so a known-traffic kernel in this library's 4-byte-per-lane access
-pattern (orbx_calibration_copy: 256 MiB read + 256 MiB written) runs in the same profile; its measured/known ratio is
+reads by 2x and other widths are uncalibrated, so a known-traffic kernel in the product kernels' 4-byte-per-lane access
+pattern (tools/calib, orbx_calibration_copy: 256 MiB read + 256 MiB written) runs in the same profile; its measured/known ratio is
 the correction applied to every kernel (reported alongside the raw numbers).
 
 Writes gpurun_out/traffic.json:  {kernel: {"launches", "fetch_raw_B", "write_raw_B", "fetch_B", "write_B", "hbm_B"}}
@@ -27,8 +27,11 @@ DRIVER = r'''
 import importlib, sys, ctypes as C
 sys.path.insert(0, %r)
 import torch
-pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
-L = pkg.load()
+import importlib.util, os
+spec = importlib.util.spec_from_file_location("orbcalib", os.path.join(%r, "tools", "calib", "calib.py"))
+calib = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(calib)
+L = calib.load()
 a = torch.randint(0, 255, (%d,), dtype=torch.uint8, device="cuda")
 b = torch.empty_like(a)
 torch.cuda.synchronize()
@@ -37,7 +40,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "256", "--streams", "1", "--batches-per-step", "4", "--groups", "2", "--no-cpu-baseline", "--no-host-fed"]
 exec(open(%r).read())
-''' % (ROOT, CALIB_BYTES, os.path.join(ROOT, "bench.py"))
+''' % (ROOT, ROOT, CALIB_BYTES, os.path.join(ROOT, "bench.py"))
 
 
 def run_pass(counter):

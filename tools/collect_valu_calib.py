@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measure the chip's vector-issue ceiling per opcode class (orbx_calibration_valu, csrc/orb_calib.h) and write
+"""Measure the chip's vector-issue ceiling per opcode class (orbx_calibration_valu, tools/calib/orb_calib.h) and write
 profiles/valu_calib.json -- the `peak` of bench.py's `valu_issue` object comes from this file, not from an assumed
 cycles-per-instruction figure.
 
@@ -10,7 +10,6 @@ chip (HIP events around the launch), shader cycles one wave-instruction occupies
 over workgroups) and the shader clock held during the run."""
 import argparse
 import ctypes as C
-import importlib
 import json
 import os
 import sys
@@ -27,11 +26,14 @@ def main():
     ap.add_argument("--ops", default="", help="comma-separated opcode-class indices (default: all)")
     ap.add_argument("--waves", default="1,2,4,8", help="resident wavefronts per SIMD to sweep")
     args = ap.parse_args()
-    pkg = importlib.import_module("3_orb_slam3_selfnote_amd")
-    L = pkg.load()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("orbcalib", os.path.join(ROOT, "tools", "calib", "calib.py"))
+    calib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(calib)
+    L = calib.load()
     nops = L.orbx_calibration_valu_ops()
     out = {"unit": "G wave-instructions/s (whole chip)", "trips": args.trips, "instructions_per_trip": 128,
-           "note": "independent instruction streams, 16 chains per lane; residency fixed by LDS; see csrc/orb_calib.h", "ops": {}}
+           "note": "independent instruction streams, 16 chains per lane; residency fixed by LDS; see tools/calib/orb_calib.h", "ops": {}}
     ops = [int(x) for x in args.ops.split(",")] if args.ops else list(range(nops))
     for op in ops:
         name = L.orbx_calibration_valu_name(op).decode()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Vector-issue ceiling of each product kernel for ITS OWN opcode mix -> profiles/valu_mix.json (runs on the CPU: hipcc -S).
 
-The per-class issue rates are measured (profiles/valu_calib.json, csrc/orb_calib.h): on gfx950 a handful of simple opcodes
+The per-class issue rates are measured (profiles/valu_calib.json, tools/calib/orb_calib.h): on gfx950 a handful of simple opcodes
 (v_add/sub_u32, v_and/or/xor_b32, v_lshrrev_b32, v_mov_b32, v_add/mul/fma_f32, v_min/max_u16, v_bitop3_b32) issue a wave64
 instruction every 2 cycles per SIMD - unless one of their sources is a scalar register, then every 4 -, nearly everything else (min/max, compares, selects, packed 16-bit, dot, perm, bcnt, mul24/mad, three-operand
 integer forms, shifts left, conversions) every 4 - and the hardware counters do not tell the two apart (SQ_ACTIVE_INST_VALU ==
