@@ -196,6 +196,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (Gloo: "Rank 0 is connected to ..."), so this process's
+    # stdout is pointed at stderr for the whole run and the line goes to a private copy of the original descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(line_fd, (json.dumps(obj) + "\n").encode())
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or leave WORLD_SIZE unset\n"
                          % (args.gpus, world, args.gpus))
@@ -220,9 +228,9 @@ def main():
             tf = shard.timed_steps(lambda: time.sleep(0.003 * (rank + 1)), 1, 0, world=world)
             hf = {"value": round(world * 48 * B / tf, 2), "unit": "frames/s", "n_gpus": world, "seconds_max_over_ranks": round(tf, 5)}
         if rank == 0:
-            print(json.dumps({"selftest": True, "metric": conf["metric"], "value": round(shard.aggregate_fps(frames_per_step, args.steps, world, dt), 2),
+            emit({"selftest": True, "metric": conf["metric"], "value": round(shard.aggregate_fps(frames_per_step, args.steps, world, dt), 2),
                               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                              "scaling": "weak", "host_fed": hf, "data": "none (ORB_BENCH_SELFTEST: no device work, launcher / barrier / MAX plumbing only)"}))
+                              "scaling": "weak", "host_fed": hf, "data": "none (ORB_BENCH_SELFTEST: no device work, launcher / barrier / MAX plumbing only)"})
         shard.finish_distributed()
         return
 
@@ -589,7 +597,7 @@ def main():
             if bad:
                 out["verify_mismatch_frames"] = bad[:16]
                 rc = 3
-        print(json.dumps(out))
+        emit(out)
         if rc:
             sys.stderr.write("bench.py: the GPU's last timed batch differs from the CPU oracle on %d frames\n" % len(bad))
     shard.finish_distributed()

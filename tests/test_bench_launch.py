@@ -22,8 +22,8 @@ def _run(extra_args, extra_env):
 def test_gpus_2_spawns_two_ranks():
     p = _run(["--gpus", "2", "--steps", "5", "--warmup", "1"], {})
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                   # rank 0 prints ONE line
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")      # ONE line on stdout, nothing else (library chatter such as Gloo's goes to stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 1 and out["scaling"] == "weak"
     # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 2 ms
