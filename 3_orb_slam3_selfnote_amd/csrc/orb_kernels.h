@@ -1101,15 +1101,23 @@ constexpr BlurTab make_blur_tab() {
 __device__ const BlurTab g_blurTab = make_blur_tab();
 
 #define BLUR_TX 128
-#define BLUR_TY 32
+#define BLUR_TY 64               // output rows per workgroup: two 32-row products that share the middle block of row sums
+#define BLUR_ROWS_IN (BLUR_TY + 6)
 #define BLURM_PITCH 176          // bytes per input tile row: 160 used (columns x0 - 16 .. x0 + 143) + one 16-byte chunk of padding
                                  // (44 dwords: 16 consecutive rows start in 16 different 4-bank groups, the A fragments read conflict-free)
 #define BLURM_OPITCH 144         // bytes per output staging row
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur(FrameParams P) {   // 60 VGPRs: the tile load is one HBM latency per workgroup, hidden only by resident workgroups
+// Workgroup = 128 x 64 outputs (late round 3; 128 x 32 before): input rows y0 - 3 .. y0 + 66 form three 32-row blocks of row sums
+// T0, T1, T2 (rows 70 .. 95 of the third only meet zero taps), output rows 0 .. 31 = V (T0, T1), rows 32 .. 63 = V (T1, T2): 6 + 8
+// products per 64 rows instead of 8 + 8, one block of row sums and byte splits less, and - what the kernel's time is made of - one HBM
+// round trip in front of twice the work.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_blur(FrameParams P) {   // seven workgroups per CU by LDS (21.5 KB each): no more than 72 registers
   typedef int v4i __attribute__((ext_vector_type(4)));
   typedef int v16i __attribute__((ext_vector_type(16)));
-  __shared__ __align__(16) uint8_t sIn[64 * BLURM_PITCH];   // rows y0 - 3 .. y0 + 34 are filled; 38 .. 63 only feed zero taps
-  __shared__ __align__(16) uint8_t sOut[32 * BLURM_OPITCH];
+  // input rows 0 .. 69, then the output staging rows: the A fragments of the third block read "rows" 70 .. 95, i.e. into the staging
+  // area - any bytes will do there, they are multiplied by zero taps
+  __shared__ __align__(16) uint8_t sLds[BLUR_ROWS_IN * BLURM_PITCH + BLUR_TY * BLURM_OPITCH];
+  static_assert(96 * BLURM_PITCH <= BLUR_ROWS_IN * BLURM_PITCH + BLUR_TY * BLURM_OPITCH, "the third block's rows must stay inside the allocation");
+  uint8_t *sIn = sLds, *sOut = sLds + BLUR_ROWS_IN * BLURM_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int tile, frame;
   xcd_map(P.totalTiles, P.magicTiles, P.nframes, frame, tile);
@@ -1123,20 +1131,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
   else { pitch = (int)(t0.w & 0xffffu); img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)t1.y << 32) | t1.x); }
   const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
-  // ---- input tile: 38 rows x 11 chunks of 16 bytes from column x0 - 16, by LDS-DMA for EVERY tile of a level that is larger than
+  // ---- input tile: 70 rows x 11 chunks of 16 bytes from column x0 - 16, by LDS-DMA for EVERY tile of a level that is larger than
   // the halo: BORDER_REFLECT_101 across the top / bottom edge is a source ROW (an address), across the left / right edge it is at
   // most three bytes per row, which a few threads copy inside the tile once the DMA has landed.  Chunks that would start outside
   // the row's memory are fetched from a clamped address (their bytes never meet a non-zero tap of a stored output, except the
-  // reflected ones).  Tiny levels and unaligned level-0 images take the byte-wise loop.
+  // reflected ones); the same holds for rows more than three below the image (clamped).  Tiny levels and unaligned level-0 images
+  // take the byte-wise loop.
   const int wlim = level == 0 ? G.w : pitch;                 // bytes of a row that may be read (level 0 is the caller's image: not past its rows)
   const bool dma = aligned && G.w >= 160 && G.h >= 40 && (wlim & 15) == 0;
   const bool edgeL = x0 == 0, edgeR = x0 + 131 >= G.w;       // some stored output of this tile needs a column left of 0 / right of w - 1
   if (dma) {
-    for (int idx = tid; idx < 38 * 11; idx += 256) {
-      const uint32_t r = mul24((uint32_t)idx, 5958u) >> 16, c = (uint32_t)idx - 11u * r;      // idx / 11, exact below 418
+    for (int idx = tid; idx < BLUR_ROWS_IN * 11; idx += 256) {
+      const uint32_t r = mul24((uint32_t)idx, 5958u) >> 16, c = (uint32_t)idx - 11u * r;      // idx / 11, exact below 770
       int yy = y0 - 3 + (int)r;
       yy = yy < 0 ? -yy : yy;
       yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy;
+      yy = max(yy, 0);
       int xb = x0 - 16 + 16 * (int)c;
       xb = min(max(xb, 0), wlim - 16);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (mul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)xb)),
@@ -1144,8 +1154,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     if (edgeL || edgeR) {
       __syncthreads();                                        // the tile has landed (the compiler drains the DMA in front of the barrier)
-      if (tid < 38 * 6) {
-        const int r = tid / 6, k = tid - 6 * r;
+      for (int i = tid; i < BLUR_ROWS_IN * 6; i += 256) {
+        const int r = (int)(mul24((uint32_t)i, 10923u) >> 16), k = i - 6 * r;      // i / 6, exact below 420
         const int x = k < 3 ? -1 - k : G.w + (k - 3);         // the column to synthesise
         const int xs = k < 3 ? 1 + k : G.w - 2 - (k - 3);     // its BORDER_REFLECT_101 source
         const bool need = k < 3 ? edgeL : (edgeR && x - (x0 - 16) < 160);
@@ -1161,8 +1171,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       else { yy = yy < 0 ? -yy : yy; yy = yy >= G.h ? 2 * (G.h - 1) - yy : yy; yy = max(yy, 0); }
       return img + mul24((uint32_t)yy, (uint32_t)pitch);
     };
-    for (int idx = tid; idx < 38 * 36; idx += 256) {          // dword columns 3 .. 38 of the 40: bytes x0 - 4 .. x0 + 139
-      const uint32_t r = mul24((uint32_t)idx, 1821u) >> 16, c = 3u + ((uint32_t)idx - r * 36u);   // idx / 36, exact below 1368
+    for (int idx = tid; idx < BLUR_ROWS_IN * 36; idx += 256) {          // dword columns 3 .. 38 of the 40: bytes x0 - 4 .. x0 + 139
+      const uint32_t r = mul24((uint32_t)idx, 1821u) >> 16, c = 3u + ((uint32_t)idx - r * 36u);   // idx / 36, exact below 2520
       const int xb = x0 - 16 + 4 * (int)c;
       const uint8_t *row = srcRow((int)r);
       uint32_t v;
@@ -1190,44 +1200,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     Va[0] = v4i{(int)q2.x, (int)q2.y, (int)q2.z, (int)q2.w}; Va[1] = v4i{(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
   }
   __syncthreads();
-  // ---- T = I H for the two 32-row halves of the tile's 64 rows, seeded with 128 * 257 so that the accumulators are the row sums
-  v16i cT, cZ, cL;
+  // ---- T = I H for a 32-row block of the tile's rows, seeded with 128 * 257 so that the accumulators are the row sums 0 .. 65535,
+  // split into (high byte - 128, low byte - 128): the second product's B fragments (element j = register j)
+  auto row_sums = [&](int mt, v4i &Bhi, v4i &Blo) {
+    // (the seed is made opaque so that every block re-materialises its 16 copies: kept alive as one constant vector across the
+    // kernel they cost 16 registers, i.e. resident wavefronts)
+    int seedT = 128 * 257;
+    asm volatile("" : "+v"(seedT));
+    v16i acc;
 #pragma unroll
-  for (int j = 0; j < 16; j++) { cT[j] = 128 * 257; cZ[j] = 0; cL[j] = 257 * 128 * 257 + 32768; }
-  v4i Bhi[2], Blo[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-    v16i acc = cT;
+    for (int j = 0; j < 16; j++) acc[j] = seedT;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       v4i a = *reinterpret_cast<const v4i *>(sIn + (32 * mt + n) * BLURM_PITCH + 32 * wid + 32 * s + 16 * hh);
       a[0] ^= (int)0x80808080; a[1] ^= (int)0x80808080; a[2] ^= (int)0x80808080; a[3] ^= (int)0x80808080;
       acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Hb[s], acc, 0, 0, 0);
     }
-    // row sums 0 .. 65535 -> (high byte - 128, low byte - 128) as the second product's B fragments (element j = register j)
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 1], (uint32_t)acc[4 * d], 0x05010400u);   // lo0 lo1 hi0 hi1
       const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)acc[4 * d + 3], (uint32_t)acc[4 * d + 2], 0x05010400u);
-      Blo[mt][d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
-      Bhi[mt][d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u);
+      Blo[d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+      Bhi[d] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u);
     }
-  }
-  // ---- O = V T: high and low bytes separately
-  v16i aH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], Bhi[0], cZ, 0, 0, 0);
-  v16i aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], Blo[0], cL, 0, 0, 0);
-  aH = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], Bhi[1], aH, 0, 0, 0);
-  aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], Blo[1], aL, 0, 0, 0);
-  // (256 aH + aL) >> 16, saturated to a byte; register j is output row rho(h, j), the lane's column is 32 w + n
+  };
+  // ---- O = V T over two blocks of row sums, high and low bytes separately; (256 aH + aL) >> 16 saturated to a byte into the staging
+  // rows row0 .. row0 + 31 (register j is output row rho(h, j), the lane's column is 32 w + n)
+  auto outputs = [&](const v4i &BhiA, const v4i &BloA, const v4i &BhiB, const v4i &BloB, int row0) {
+    // ONE accumulator: the high-byte product first, then 256 * aH + the rounding constant is the C operand of the low-byte product
+    // (two accumulators side by side cost 16 more registers, i.e. two resident wavefronts per SIMD)
+    v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], BhiA, v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], BhiB, acc, 0, 0, 0);
+    int seedL = 257 * 128 * 257 + 32768;
+    asm volatile("" : "+v"(seedL));
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const uint32_t v = ((uint32_t)aH[j] << 8) + (uint32_t)aL[j];
-    const uint32_t b = min(v >> 16, 255u);
-    sOut[((j & 3) + 8 * (j >> 2) + 4 * hh) * BLURM_OPITCH + 32 * wid + n] = (uint8_t)b;
+    for (int j = 0; j < 16; j++) acc[j] = (int)(((uint32_t)acc[j] << 8) + (uint32_t)seedL);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[0], BloA, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Va[1], BloB, acc, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t b = min((uint32_t)acc[j] >> 16, 255u);
+      sOut[(row0 + (j & 3) + 8 * (j >> 2) + 4 * hh) * BLURM_OPITCH + 32 * wid + n] = (uint8_t)b;
+    }
+  };
+  // (the scheduling barriers keep the phases apart: interleaved, their accumulators need 84 registers instead of 64 and cost three
+  // resident wavefronts per SIMD)
+  v4i H0, L0, H1, L1;
+  row_sums(0, H0, L0);
+  __builtin_amdgcn_sched_barrier(0);
+  row_sums(1, H1, L1);
+  __builtin_amdgcn_sched_barrier(0);
+  outputs(H0, L0, H1, L1, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (y0 + 32 < G.h) {                       // the lower half exists (uniform)
+    row_sums(2, H0, L0);
+    __builtin_amdgcn_sched_barrier(0);
+    outputs(H1, L1, H0, L0, 32);
   }
   __syncthreads();
-  {
-    const int row = tid >> 3, seg = tid & 7;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int row = (tid >> 3) + 32 * t, seg = tid & 7;
     const int y = y0 + row, x = x0 + 16 * seg;
     if (y < G.h && x < G.w) {
       uint8_t *out = P.blur + (size_t)frame * P.blur_fs + G.boff + (size_t)y * G.bpitch + x;
