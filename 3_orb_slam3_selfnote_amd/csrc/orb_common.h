@@ -41,7 +41,8 @@ struct LevelGeom {
   float kpsize;      // (float)(int)(PATCH_SIZE*scale), :862
   // resize tables (level >= 1): index into xtab/ytab
   int xtabBase, ytabBase;
-  int resizeSrcRows; // most source rows any RESIZE_ROWS-row tile of this level reads (host: sizes k_resize's LDS stage)
+  int resizeRows;    // output rows per k_resize workgroup of this level: 16, or 8 when the 16-row LDS stage would not fit (host)
+  int resizeSrcRows; // most source rows any resizeRows-row tile of this level reads (host: sizes k_resize's LDS stage)
   // blur tiles
   int tilesX, tilesY, tileBase;
   uint32_t rowTileMagic;  // floor(2^32 / row tiles of k_resize), see xcd_map

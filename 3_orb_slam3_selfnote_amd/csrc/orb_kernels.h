@@ -151,31 +151,35 @@ __device__ uint32_t lds_excl_scan(uint32_t *a, int n, uint32_t *sw) {
 // K1: cv::resize INTER_LINEAR 8UC1.  Level `level` of every frame from level-1.
 // Tables {sx, a0|a1<<16} / {sy, b0|b1<<16} are built on the host (orbx_configure); the result is
 //   (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2,   r = S[sy][sx] * a0 + S[sy][sx + 1] * a1   for rows sy, sy + 1.
-// Workgroup = RESIZE_ROWS output rows x full width.
+// Workgroup = G.resizeRows (16 or 8) output rows x full width.
 //
 // Two-pass form (tPitch > 0, the host's choice whenever a tile's source rows fit the LDS stage): the horizontal interpolation r >> 4
 // of a source row is shared by the two output rows that straddle it, so it is evaluated once per (source row, output column) -
-// about 1.4 per output pixel for 8-row tiles at scale 1.2 instead of 2 - into a 16-bit LDS plane T, and the vertical pass reads
+// about 1.35 per output pixel for 16-row tiles at scale 1.2 instead of 2 - into a 16-bit LDS plane T, and the vertical pass reads
 // four finished values with one 8-byte LDS load (SQ_INSTS_VALU per launch 13.3 M -> 9.8 M against the one-pass gather form).
 // One-pass form (tPitch == 0): extreme scale factors, straight from global memory.
 // ------------------------------------------------------------------------------------------------------------
-#define RESIZE_ROWS 8
-#define RESIZE_MAXSRC 16   // most source rows per tile the two-pass form stages: floor(1.2*(RESIZE_ROWS-1)) + 2 with margin (scale <= 1.6)
+// Output rows per workgroup: 16 (late round 3; 8 before) - a tile's source rows come in with ONE HBM round trip, and twice the rows
+// behind it is twice the work per wait (the same reasoning as k_blur's 64-row tiles); alone on the chip the kernel is as fast as before,
+// beside the other pipelines the step gains 2 % (16: 208-211 k frames/s, 8: 204-207 k, 24: 206 k, 32: 201 k).  Levels whose 16-row stage
+// would not fit the LDS (images wider than ~2600 columns) take 8-row tiles (G.resizeRows, decided in orbx_configure).
+#define RESIZE_ROWS_MAX 16
+#define RESIZE_MAXSRC 32   // most source rows per tile the two-pass form stages (16 rows at scale 2: 32)
 __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int smemRowBytes, int tPitch, int maxSrc) {
   extern __shared__ __align__(16) uint8_t smem_rs[];
   const LevelGeom G = P.geom[level];
   const LevelGeom Gs = P.geom[level - 1];
   const int tid = threadIdx.x;
   int frame, rowTile;
-  xcd_map((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS, G.rowTileMagic, P.nframes, frame, rowTile);
-  const int dy0 = rowTile * RESIZE_ROWS;
-  const int nrows = min(RESIZE_ROWS, G.h - dy0);
+  xcd_map((G.h + G.resizeRows - 1) / G.resizeRows, G.rowTileMagic, P.nframes, frame, rowTile);
+  const int dy0 = rowTile * G.resizeRows;
+  const int nrows = min(G.resizeRows, G.h - dy0);
   int spitch;
   const uint8_t *src = level_plane(P, frame, level - 1, spitch);
   uint8_t *dstplane = P.pyr + (size_t)frame * P.pyr_fs + G.off;
   const int wq = (G.w + 3) & ~3, qw = wq >> 2;   // the x table is padded to whole output quads with copies of its last entry (host)
   // the tile's y-coefficients go through LDS: the row code below then has no global load in front of it
-  __shared__ int2 sY[RESIZE_ROWS];
+  __shared__ int2 sY[RESIZE_ROWS_MAX];
   if (tid < nrows) sY[tid] = P.ytab[G.ytabBase + dy0 + tid];
 
   if (tPitch > 0) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
     const int nsrc = min(syLast - syFirst + 1, maxSrc);
     uint8_t *sRows = smem_rs;                                  // [maxSrc][smemRowBytes]
     uint8_t *sT = sRows + (size_t)maxSrc * smemRowBytes;       // [maxSrc][tPitch] bytes, u16 entries
-    uint4 *sRowRec = reinterpret_cast<uint4 *>(sT + (size_t)maxSrc * tPitch);   // [RESIZE_ROWS]
+    uint4 *sRowRec = reinterpret_cast<uint4 *>(sT + (size_t)maxSrc * tPitch);   // [RESIZE_ROWS_MAX]
     // this thread's first two column pairs of pass 1, loaded ahead of the staging (a level up to 1024 columns wide needs no more)
     const int4 *xtab4 = reinterpret_cast<const int4 *>(P.xtab + G.xtabBase);
     int4 xtPre[2];
@@ -279,13 +283,11 @@ __global__ __launch_bounds__(256) void k_resize(FrameParams P, int level, int sm
       }
     }
     __syncthreads();
-    // Pass 2: 32 threads per output row (RESIZE_ROWS x 32 = the workgroup), each 4 consecutive output pixels per trip: everything that
+    // Pass 2: 32 threads per output row, eight rows at a time, each 4 consecutive output pixels per trip: everything that
     // depends on the row alone is read once, a trip is two 8-byte LDS loads, the arithmetic and one 32-bit store.  No saturate_cast
     // needed: the coefficients are non-negative and each pair sums to 2048, so v is a convex combination of four bytes, rounded
     // down-ish: always inside [0, 255].
-    static_assert(RESIZE_ROWS * 32 == 256, "pass 2 maps 32 threads to each output row of the tile");
-    const int ry = tid >> 5;
-    if (ry < nrows) {
+    for (int ry = tid >> 5; ry < nrows; ry += 8) {
       const uint4 rec = sRowRec[ry];
       const uint32_t b0 = rec.z & 0xffffu, b1 = rec.z >> 16;
       const uint8_t *T0 = sT + rec.x, *T1 = sT + rec.y;

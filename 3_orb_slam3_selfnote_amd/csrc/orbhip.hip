@@ -408,20 +408,29 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         int b1 = std::min(std::max(cv_round(fy * 2048), -32768), 32767);
         ytab.push_back(make_int2(sy, (b0 & 0xffff) | (b1 << 16)));
       }
-      G.resizeSrcRows = 0;
-      for (int dy0 = 0; dy0 < G.h; dy0 += RESIZE_ROWS) {   // as k_resize derives a tile's source rows
-        const int nrows = std::min(RESIZE_ROWS, G.h - dy0);
-        const int f = std::min(std::max(ytab[G.ytabBase + dy0].x, 0), sh - 1), la = std::min(std::max(ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), sh - 1);
-        G.resizeSrcRows = std::max(G.resizeSrcRows, la - f + 1);
-      }
-    }
+      // k_resize's tile height: 16 output rows while the LDS stage of a tile (its source rows + their horizontally interpolated rows)
+      // stays below 64 KB - two workgroups per CU beside everything else -, else 8
+      auto src_rows = [&](int rows) {
+        int m = 0;
+        for (int dy0 = 0; dy0 < G.h; dy0 += rows) {   // as k_resize derives a tile's source rows
+          const int nrows = std::min(rows, G.h - dy0);
+          const int f = std::min(std::max(ytab[G.ytabBase + dy0].x, 0), sh - 1), la = std::min(std::max(ytab[G.ytabBase + dy0 + nrows - 1].x + 1, 0), sh - 1);
+          m = std::max(m, la - f + 1);
+        }
+        return m;
+      };
+      const size_t rowStage = align_up((size_t)sw + 4, 16) + align_up((size_t)((G.w + 3) & ~3) * 2, 8);
+      G.resizeRows = RESIZE_ROWS_MAX;
+      G.resizeSrcRows = src_rows(G.resizeRows);
+      if ((size_t)G.resizeSrcRows * rowStage > 64 * 1024 || G.resizeSrcRows > RESIZE_MAXSRC) { G.resizeRows = 8; G.resizeSrcRows = src_rows(8); }
+    } else { G.resizeRows = RESIZE_ROWS_MAX; G.resizeSrcRows = 0; }
   }
   if (slots > (1 << 30)) { h->err = "workspace too large"; return ORBX_E_ARG; }
   // FAST cell records (k_fast): window of every cell as the reference's double loop derives it, ORBextractor.cc:787-803
   std::vector<uint32_t> cellrec((size_t)std::max(cells, 1) * 8, 0u);
   for (int l = 0; l < nl; l++) {
     LevelGeom &G = g[l];
-    G.rowTileMagic = magic_div((uint32_t)((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS));
+    G.rowTileMagic = magic_div((uint32_t)((G.h + G.resizeRows - 1) / G.resizeRows));
     for (int ci = 0; ci < G.nRows; ci++)
       for (int cj = 0; cj < G.nCols; cj++) {
         const int c = ci * G.nCols + cj;
@@ -653,11 +662,11 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     // otherwise the one-pass form straight from global memory (tPitch 0), which stages the x table only.
     const int wq = (G.w + 3) & ~3;
     const int tPitch2 = (int)align_up((size_t)wq * 2, 8);                  // horizontally interpolated rows, 16 bits per column
-    const size_t lds2 = (size_t)G.resizeSrcRows * (rowBytes + tPitch2) + 16 * RESIZE_ROWS;
+    const size_t lds2 = (size_t)G.resizeSrcRows * (rowBytes + tPitch2) + 16 * RESIZE_ROWS_MAX;
     const bool twoPass = G.resizeSrcRows <= RESIZE_MAXSRC && (double)Gs.w / G.w < 3.0 && lds2 <= ORB_LDS_LIMIT - 1024;   // (very wide images: one-pass)
     const int tPitch = twoPass ? tPitch2 : 0;
     const size_t lds = twoPass ? lds2 : (size_t)wq * 8;
-    hipLaunchKernelGGL(k_resize, dim3(((G.h + RESIZE_ROWS - 1) / RESIZE_ROWS) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch, G.resizeSrcRows);
+    hipLaunchKernelGGL(k_resize, dim3(((G.h + G.resizeRows - 1) / G.resizeRows) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch, G.resizeSrcRows);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
   if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
