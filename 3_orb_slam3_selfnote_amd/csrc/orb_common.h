@@ -14,7 +14,7 @@
 // 16-byte chunks: the tile is filled by global_load_lds_dwordx4, whose LDS image is lane-linear (no padding between rows).
 #define FAST_TILE_PITCH 80
 #define FAST_TILE_COLS 65      // widest cell window (interior 59 + 6)
-#define FAST_TILE_ROWS 66
+#define FAST_TILE_ROWS 76      // tallest group window: two cells of up to 35 rows + 6 (a single cell: up to 59 + 6)
 #define FAST_S_PITCH 64  // score plane incl. 1-px zero ring: <= 61 columns
 
 // Geometry of one pyramid level; filled on the host (orbx_configure), read by every kernel.
@@ -84,6 +84,9 @@ struct FrameParams {
   uint32_t magicCells, magicTiles, magicKpBlk;  // floor(2^32 / items per frame) of k_fast, k_blur, k_describe (xcd_map)
   int totalTiles;                   // blur tiles per frame
   int totalCells;                   // FAST cells per frame
+  int totalGroups;                  // k_fast workgroups per frame: groups of up to 2 x 2 neighbouring cells
+  uint32_t magicGroups;             // floor(2^32 / totalGroups), xcd_map
+  const uint32_t *groups;           // 4 words per group: first cell | gx, gy, cell-row stride | tile origin | tile size, level, valid
   int totalKp;                      // sum of kpCap
   int octCap;                       // node capacity of the octree kernel
   const ChainTile *chain;           // k_pyramid_chain's tile records

@@ -489,18 +489,59 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
 #ifdef FAST_STAMPS
   long long ft0 = __builtin_readcyclecounter();
 #endif
-  __shared__ __align__(16) uint8_t sT[FAST_TILE_ROWS * FAST_TILE_PITCH];
+  __shared__ __align__(16) uint8_t sTile[FAST_TILE_ROWS * FAST_TILE_PITCH];
   __shared__ __align__(16) uint8_t sS[62 * FAST_S_PITCH];
   __shared__ uint16_t sList[4 * FAST_LIST_SEG];
   __shared__ __align__(16) uint32_t sWCount[12];   // [0..3] pass-1 list segments, [4..11] two count buffers of the ordered compactions
   const int tid = threadIdx.x, lane = tid & 63;
-  int cellId, frame;
-  xcd_map(P.totalCells, P.magicCells, P.nframes, frame, cellId);
+  // A workgroup takes a GROUP of up to 2 x 2 neighbouring cells (late round 3; one cell before): their windows overlap by six pixels and
+  // the 80-byte tile rows always carried the right-hand neighbour's columns, so one staged tile - one HBM round trip, one set of
+  // address arithmetic - now serves four cells, which are then detected one after the other with the per-cell code unchanged (the
+  // reference decides iniThFAST / minThFAST per cell, ORBextractor.cc:820-828).  Group records come from orbx_configure.
+  int groupId, frame;
+  xcd_map(P.totalGroups, P.magicGroups, P.nframes, frame, groupId);
+  const uint4 gr = reinterpret_cast<const uint4 *>(P.groups)[groupId];
+  const int firstCell = (int)gr.x, gx = (int)(gr.y & 0xffu), gy = (int)((gr.y >> 8) & 0xffu), gStride = (int)(gr.y >> 16);
+  const int tileX = (int)(gr.z & 0xffffu), tileY = (int)(gr.z >> 16);
+  const int gtw = (int)(gr.w & 0xffu), gth = (int)((gr.w >> 8) & 0xffu), level = (int)((gr.w >> 16) & 0xffu);
+  const bool gvalid = (gr.w >> 24) != 0u;
+  int pitch = 0;
+  const uint8_t *img = nullptr;
+  const int ax = tileX & ~3;                          // tile column 0 = image column ax, tile row 0 = image row tileY
+  if (gvalid) {
+    const uint4 r1f = reinterpret_cast<const uint4 *>(P.cells)[2 * firstCell + 1];
+    if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
+    else { pitch = (int)r1f.y; img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)r1f.w << 32) | r1f.z); }
+    // ---- tile -> LDS.  Aligned path: the columns [tileX & ~3, ...) of the group's rows.
+    const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
+    if (aligned) {
+      // LDS-DMA: one global_load_lds_dwordx4 per lane moves 16 bytes straight into the tile (no register, no ds_write); the
+      // tile is lane-linear, chunk idx = 5 * row + chunk-in-row.  Chunks past the group's columns read the bytes that follow
+      // in the plane (a cell window ends >= 13 rows above the plane's last row, so they exist) and are never looked at.
+      // Index arithmetic in 24-bit multiplies (full rate): idx / 5 as (idx * 13108) >> 16, exact below 5 * FAST_TILE_ROWS.
+      const int nch = 5 * gth;
+      const uint8_t *img0 = img + mul24((uint32_t)tileY, (uint32_t)pitch) + ax;
+      for (int idx = tid; idx < nch; idx += FAST_NT) {
+        const uint32_t r = mul24((uint32_t)idx, 13108u) >> 16, c = (uint32_t)idx - 5u * r;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img0 + (mul24(r, (uint32_t)pitch) + 16u * c)),
+                                         (__attribute__((address_space(3))) void *)&sTile[idx * 16], 16, 0, 0);
+      }
+    } else {
+      const uint32_t magic = (1u << 20) / (uint32_t)gtw + 1u;
+      const int ox0 = tileX - ax;
+      const uint8_t *img0 = img + mul24((uint32_t)tileY, (uint32_t)pitch) + tileX;
+      for (int idx = tid; idx < gtw * gth; idx += FAST_NT) {
+        const uint32_t r = mul24((uint32_t)idx, magic) >> 20, cc = (uint32_t)idx - mul24(r, (uint32_t)gtw);
+        sTile[r * FAST_TILE_PITCH + ox0 + cc] = img0[mul24(r, (uint32_t)pitch) + cc];
+      }
+    }
+  }
+  auto do_cell = [&](const int cellId) {
   // cell record (orbx_configure, ORBextractor.cc:787-803): one 32-byte scalar load instead of a level search plus
   // a dozen dependent geometry loads per workgroup
   const uint4 r0 = reinterpret_cast<const uint4 *>(P.cells)[2 * cellId], r1 = reinterpret_cast<const uint4 *>(P.cells)[2 * cellId + 1];
   const int iniX = (int)(r0.x & 0xffffu), iniY = (int)(r0.x >> 16);
-  const int tw = (int)(r0.y & 0xffu), th = (int)((r0.y >> 8) & 0xffu), level = (int)((r0.y >> 16) & 0xffu), cw = tw - 6, ch = th - 6;
+  const int tw = (int)(r0.y & 0xffu), th = (int)((r0.y >> 8) & 0xffu), cw = tw - 6, ch = th - 6;
   const uint32_t baseX = r0.z & 0xffffu, baseY = r0.z >> 16;  // cj * wCell, ci * hCell
   const uint32_t cellCap = r1.x;
   uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cell_fs + cellId;
@@ -508,34 +549,8 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
     if (tid == 0) *cellCnt = 0;
     return;
   }
-  int pitch;
-  const uint8_t *img;
-  if (level == 0) { pitch = (int)P.img0_stride; img = P.img0 + (size_t)frame * P.img0_frame_stride; }
-  else { pitch = (int)r1.y; img = P.pyr + (size_t)frame * P.pyr_fs + (((size_t)r1.w << 32) | r1.z); }
-
-  // ---- tile -> LDS.  Aligned path: dword loads of the columns [iniX & ~3, ...), tile column 0 = image column ax.
-  const int ax = iniX & ~3, ox = iniX - ax;           // ox: offset of the cell's first column inside the tile
-  const bool aligned = ((((uintptr_t)img) | (uintptr_t)pitch) & 3u) == 0;
-  if (aligned) {
-    // LDS-DMA: one global_load_lds_dwordx4 per lane moves 16 bytes straight into the tile (no register, no ds_write); the
-    // tile is lane-linear, chunk idx = 5 * row + chunk-in-row.  Chunks past the cell's columns read the bytes that follow
-    // in the plane (a cell window ends >= 13 rows above the plane's last row, so they exist) and are never looked at.
-    // Index arithmetic in 24-bit multiplies (full rate): idx / 5 as (idx * 13108) >> 16, exact below 330 = 5 * 66.
-    const int nch = 5 * th;
-    const uint8_t *img0 = img + mul24((uint32_t)iniY, (uint32_t)pitch) + ax;
-    for (int idx = tid; idx < nch; idx += FAST_NT) {
-      const uint32_t r = mul24((uint32_t)idx, 13108u) >> 16, c = (uint32_t)idx - 5u * r;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img0 + (mul24(r, (uint32_t)pitch) + 16u * c)),
-                                       (__attribute__((address_space(3))) void *)&sT[idx * 16], 16, 0, 0);
-    }
-  } else {
-    const uint32_t magic = (1u << 20) / (uint32_t)tw + 1u;
-    const uint8_t *img0 = img + mul24((uint32_t)iniY, (uint32_t)pitch) + iniX;
-    for (int idx = tid; idx < tw * th; idx += FAST_NT) {
-      const uint32_t r = mul24((uint32_t)idx, magic) >> 20, cc = (uint32_t)idx - mul24(r, (uint32_t)tw);
-      sT[r * FAST_TILE_PITCH + ox + cc] = img0[mul24(r, (uint32_t)pitch) + cc];
-    }
-  }
+  const int ox = iniX - ax;                                          // offset of the cell's first column inside the tile
+  const uint8_t *sT = sTile + (iniY - tileY) * FAST_TILE_PITCH;      // the cell's first row inside the tile
   // score plane rows 0 .. ch+1 to zero: (ch + 2) * 64 bytes = at most 244 sixteen-byte stores, one per thread, no loop
   static_assert(62 * FAST_S_PITCH / 16 <= FAST_NT, "one 16-byte store per thread must cover the score plane");
   if (tid < ((ch + 2) * FAST_S_PITCH) / 16) reinterpret_cast<uint4 *>(sS)[tid] = make_uint4(0u, 0u, 0u, 0u);
@@ -658,6 +673,12 @@ __global__ __launch_bounds__(FAST_NT) void k_fast(FrameParams P) {
   }
   if (tid == 0) *cellCnt = (uint32_t)min(nkept, (int)cellCap);
   FSTAMP(7);
+  };
+  for (int cy = 0; cy < gy; cy++)
+    for (int cx = 0; cx < gx; cx++) {
+      if (cy | cx) __syncthreads();      // the previous cell is done with the score plane, the lists and the counters
+      do_cell(firstCell + cy * gStride + cx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -82,10 +82,10 @@ struct orbx_handle {
   int chainTiles = 0, chainBuf0 = 0, chainBuf1 = 0;   // k_pyramid_chain (single-frame calls); chainTiles = 0: not available
   size_t chainLds = 0;
   size_t octLds = 0;
-  int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalKp = 0, octCap = 0;
+  int cell_fs = 0, cand_fs = 0, lkp_fs = 0, totalTiles = 0, totalCells = 0, totalGroups = 0, totalKp = 0, octCap = 0;
   int maxKeypoints = 0;
   // device memory
-  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_tiles, d_xtab,
+  DevBuf d_pyr, d_blur, d_cellCnt, d_cellOff, d_slots, d_cand, d_knode, d_lkp, d_lrank, d_lcnt, d_candCnt, d_cells, d_groups, d_tiles, d_xtab,
       d_ytab, d_disc, d_chain;
   DevBuf d_img, d_okps;  // staging for the host entry point (d_okps: counts + keypoints + descriptors, one block)
   hipStream_t stream = nullptr;
@@ -261,7 +261,7 @@ void orbx_destroy(orbx_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_pyr, &h->d_blur, &h->d_cellCnt, &h->d_cellOff, &h->d_slots, &h->d_cand, &h->d_knode, &h->d_lkp,
-                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_chain, &h->d_img, &h->d_okps};
+                    &h->d_lrank, &h->d_lcnt, &h->d_candCnt, &h->d_cells, &h->d_groups, &h->d_tiles, &h->d_xtab, &h->d_ytab, &h->d_disc, &h->d_chain, &h->d_img, &h->d_okps};
   for (DevBuf *b : bufs) b->release();
   for (DevBuf &b : h->stereo) b.release();
   for (DevBuf &b : h->maps) b.release();
@@ -450,6 +450,36 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
         R[7] = (uint32_t)((uint64_t)G.off >> 32);
       }
   }
+  // k_fast's workgroups: groups of up to 2 x 2 neighbouring cells of a level that fit one LDS tile (80-byte rows from the first cell's
+  // column rounded down to 4, FAST_TILE_ROWS rows); levels with larger cells keep one cell per group in that direction
+  std::vector<uint32_t> grouprec;
+  for (int l = 0; l < nl; l++) {
+    const LevelGeom &G = g[l];
+    const int sx = (3 + 2 * G.wCell + 6 <= FAST_TILE_PITCH) ? 2 : 1, sy = (2 * G.hCell + 6 <= FAST_TILE_ROWS) ? 2 : 1;
+    for (int ci = 0; ci < G.nRows; ci += sy)
+      for (int cj = 0; cj < G.nCols; cj += sx) {
+        const int gx = std::min(sx, G.nCols - cj), gy = std::min(sy, G.nRows - ci);
+        const int first = G.cellBase + ci * G.nCols + cj;
+        const uint32_t *F = &cellrec[(size_t)first * 8];
+        const int tileX = (int)(F[0] & 0xffffu), tileY = (int)(F[0] >> 16);
+        int maxX = 0, maxY = 0, nvalid = 0;
+        for (int a = 0; a < gy; a++)
+          for (int b = 0; b < gx; b++) {
+            const uint32_t *R = &cellrec[(size_t)(first + a * G.nCols + b) * 8];
+            if (!(R[1] >> 24)) continue;
+            nvalid++;
+            maxX = std::max(maxX, (int)(R[0] & 0xffffu) + (int)(R[1] & 0xffu));
+            maxY = std::max(maxY, (int)(R[0] >> 16) + (int)((R[1] >> 8) & 0xffu));
+          }
+        const int gtw = nvalid ? maxX - tileX : 0, gth = nvalid ? maxY - tileY : 0;
+        if (nvalid && ((tileX & 3) + gtw > FAST_TILE_PITCH || gth > FAST_TILE_ROWS)) { h->err = "FAST cell group larger than the LDS tile"; return ORBX_E_ARG; }
+        grouprec.push_back((uint32_t)first);
+        grouprec.push_back((uint32_t)gx | ((uint32_t)gy << 8) | ((uint32_t)G.nCols << 16));
+        grouprec.push_back((uint32_t)tileX | ((uint32_t)tileY << 16));
+        grouprec.push_back((uint32_t)gtw | ((uint32_t)gth << 8) | ((uint32_t)l << 16) | (nvalid ? 1u << 24 : 0u));
+      }
+  }
+  h->totalGroups = (int)(grouprec.size() / 4);
   // blur tile records (k_blur)
   std::vector<uint32_t> tilerec((size_t)std::max(tiles, 1) * 8, 0u);
   for (int l = 0; l < nl; l++) {
@@ -493,6 +523,8 @@ int orbx_configure(orbx_t *h, int rows, int cols, int max_batch) {
   XCHECK(h, h->d_candCnt.reserve(sizeof(int32_t) * nl * B));
   XCHECK(h, h->d_cells.reserve(sizeof(uint32_t) * cellrec.size()));
   XCHECK(h, copy_on(h->stream, h->d_cells.p, cellrec.data(), sizeof(uint32_t) * cellrec.size(), hipMemcpyHostToDevice));
+  XCHECK(h, h->d_groups.reserve(sizeof(uint32_t) * std::max<size_t>(grouprec.size(), 4)));
+  if (!grouprec.empty()) XCHECK(h, copy_on(h->stream, h->d_groups.p, grouprec.data(), sizeof(uint32_t) * grouprec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_tiles.reserve(sizeof(uint32_t) * tilerec.size()));
   XCHECK(h, copy_on(h->stream, h->d_tiles.p, tilerec.data(), sizeof(uint32_t) * tilerec.size(), hipMemcpyHostToDevice));
   XCHECK(h, h->d_xtab.reserve(sizeof(int2) * std::max<size_t>(xtab.size(), 1)));
@@ -635,6 +667,9 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
   P.totalTiles = h->totalTiles;
   P.totalCells = h->totalCells;
   P.cells = (const uint32_t *)h->d_cells.p;
+  P.groups = (const uint32_t *)h->d_groups.p;
+  P.totalGroups = h->totalGroups;
+  P.magicGroups = magic_div((uint32_t)std::max(h->totalGroups, 1));
   P.tiles = (const uint32_t *)h->d_tiles.p;
   P.magicCells = magic_div((uint32_t)std::max(h->totalCells, 1));
   P.magicTiles = magic_div((uint32_t)std::max(h->totalTiles, 1));
@@ -669,7 +704,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_images, int rows, int 
     hipLaunchKernelGGL(k_resize, dim3(((G.h + G.resizeRows - 1) / G.resizeRows) * nframes), dim3(256), lds, s, P, l, rowBytes, tPitch, G.resizeSrcRows);
   }
   if (prof) XCHECK(h, hipEventRecord(pev[1], s));
-  if (h->totalCells > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalCells * nframes), dim3(FAST_NT), 0, s, P);
+  if (h->totalGroups > 0) hipLaunchKernelGGL(k_fast, dim3(h->totalGroups * nframes), dim3(FAST_NT), 0, s, P);
   if (prof) XCHECK(h, hipEventRecord(pev[2], s));
   // (k_octree: one workgroup per (frame, level); a single frame has only nlevels of them and the longest, level 0, is the critical
   // path of the whole call, so few-frame launches use 1024 threads per workgroup)
