@@ -1124,7 +1124,9 @@ constexpr BlurTab make_blur_tab() {
 __device__ const BlurTab g_blurTab = make_blur_tab();
 
 #define BLUR_TX 128
-#define BLUR_TY 64               // output rows per workgroup: two 32-row products that share the middle block of row sums
+#ifndef BLUR_TY
+#define BLUR_TY 64               // output rows per workgroup: 32-row products, neighbours share a block of row sums
+#endif
 #define BLUR_ROWS_IN (BLUR_TY + 6)
 #define BLURM_PITCH 176          // bytes per input tile row: 160 used (columns x0 - 16 .. x0 + 143) + one 16-byte chunk of padding
                                  // (44 dwords: 16 consecutive rows start in 16 different 4-bank groups, the A fragments read conflict-free)
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
   // input rows 0 .. 69, then the output staging rows: the A fragments of the third block read "rows" 70 .. 95, i.e. into the staging
   // area - any bytes will do there, they are multiplied by zero taps
   __shared__ __align__(16) uint8_t sLds[BLUR_ROWS_IN * BLURM_PITCH + BLUR_TY * BLURM_OPITCH];
-  static_assert(96 * BLURM_PITCH <= BLUR_ROWS_IN * BLURM_PITCH + BLUR_TY * BLURM_OPITCH, "the third block's rows must stay inside the allocation");
+  static_assert(BLUR_TY % 32 == 0 && (BLUR_TY + 32) * BLURM_PITCH <= BLUR_ROWS_IN * BLURM_PITCH + BLUR_TY * BLURM_OPITCH, "the last block's rows must stay inside the allocation");
   uint8_t *sIn = sLds, *sOut = sLds + BLUR_ROWS_IN * BLURM_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int tile, frame;
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
       return img + mul24((uint32_t)yy, (uint32_t)pitch);
     };
     for (int idx = tid; idx < BLUR_ROWS_IN * 36; idx += 256) {          // dword columns 3 .. 38 of the 40: bytes x0 - 4 .. x0 + 139
-      const uint32_t r = mul24((uint32_t)idx, 1821u) >> 16, c = 3u + ((uint32_t)idx - r * 36u);   // idx / 36, exact below 2520
+      const uint32_t r = mul24((uint32_t)idx, 3641u) >> 17, c = 3u + ((uint32_t)idx - r * 36u);   // idx / 36, exact below 4824
       const int xb = x0 - 16 + 4 * (int)c;
       const uint8_t *row = srcRow((int)r);
       uint32_t v;
@@ -1268,21 +1270,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
   };
   // (the scheduling barriers keep the phases apart: interleaved, their accumulators need 84 registers instead of 64 and cost three
   // resident wavefronts per SIMD)
-  v4i H0, L0, H1, L1;
-  row_sums(0, H0, L0);
-  __builtin_amdgcn_sched_barrier(0);
-  row_sums(1, H1, L1);
-  __builtin_amdgcn_sched_barrier(0);
-  outputs(H0, L0, H1, L1, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if (y0 + 32 < G.h) {                       // the lower half exists (uniform)
-    row_sums(2, H0, L0);
+  v4i Hp, Lp, Hc, Lc;
+  row_sums(0, Hp, Lp);
+#pragma unroll
+  for (int k = 0; k < BLUR_TY / 32; k++) {
+    if (k > 0 && y0 + 32 * k >= G.h) break;      // no output row down there (uniform)
     __builtin_amdgcn_sched_barrier(0);
-    outputs(H1, L1, H0, L0, 32);
+    row_sums(k + 1, Hc, Lc);
+    __builtin_amdgcn_sched_barrier(0);
+    outputs(Hp, Lp, Hc, Lc, 32 * k);
+    Hp = Hc; Lp = Lc;
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
+  for (int t = 0; t < BLUR_TY / 32; t++) {
     const int row = (tid >> 3) + 32 * t, seg = tid & 7;
     const int y = y0 + row, x = x0 + 16 * seg;
     if (y < G.h && x < G.w) {
